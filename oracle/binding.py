@@ -1,0 +1,214 @@
+"""ctypes bindings for the two CPU checkers.  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this
+module; nothing under `chunkyclplugin_amd/` does.
+
+* `ref()`  — oracle/_ref/libchunky_ref.so: the reference OpenCL kernel itself, compiled in place
+             from /root/reference for x86-64 (exists only where it was built; travels as a
+             prebuilt file to the GPU box).
+* `port()` — oracle/libchunky_port.so: oracle/port.c, the plain-C restatement (buildable
+             anywhere with gcc).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_TRACES = 10
+
+
+class OracleScene(C.Structure):
+    _fields_ = [
+        ("projector_type", C.c_int32), ("camera_settings", C.c_void_p),
+        ("octree_depth", C.c_int32), ("octree", C.c_void_p),
+        ("block_palette", C.c_void_p), ("quad_models", C.c_void_p), ("aabb_models", C.c_void_p),
+        ("world_bvh", C.c_void_p), ("actor_bvh", C.c_void_p), ("bvh_trigs", C.c_void_p),
+        ("atlas", C.c_void_p), ("atlas_w", C.c_int32), ("atlas_h", C.c_int32), ("atlas_layers", C.c_int32),
+        ("material_palette", C.c_void_p),
+        ("sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32), ("sky_intensity", C.c_float),
+        ("sun", C.c_void_p),
+        ("width", C.c_int32), ("height", C.c_int32),
+    ]
+
+
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("material", "<i4"), ("distance", "<f4"), ("normal", "<f4", 3),
+                      ("color", "<f4", 4), ("emittance", "<f4"), ("point", "<f4", 3)])
+assert HIT_DTYPE.itemsize == 56
+
+COUNTER_NAMES = ("samples", "traces", "steps", "node", "block", "model_hdr", "aabb", "quad", "mat",
+                 "texel", "bvh_inner", "leaf_hdr", "tri", "sky", "hits")
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+class SceneHandle:
+    """Keeps the numpy arrays alive and exposes the OracleScene struct."""
+
+    def __init__(self, sc):
+        self.keep = dict(
+            cam=np.ascontiguousarray(sc.camera, np.float32),
+            octree=np.ascontiguousarray(sc.octree, np.int32),
+            blocks=np.ascontiguousarray(sc.block_palette, np.int32),
+            quads=np.ascontiguousarray(sc.quad_models, np.int32),
+            aabbs=np.ascontiguousarray(sc.aabb_models, np.int32),
+            wbvh=np.ascontiguousarray(sc.world_bvh, np.int32),
+            abvh=np.ascontiguousarray(sc.actor_bvh, np.int32),
+            trigs=np.ascontiguousarray(sc.bvh_trigs, np.int32),
+            atlas=np.ascontiguousarray(sc.atlas, np.uint8),
+            mats=np.ascontiguousarray(sc.material_palette, np.int32),
+            sky=np.ascontiguousarray(sc.sky, np.uint8),
+            sun=np.ascontiguousarray(sc.sun, np.int32),
+        )
+        k = self.keep
+        L, H, W, _ = k["atlas"].shape
+        self.struct = OracleScene(
+            int(sc.projector_type), _ptr(k["cam"]), int(sc.octree_depth), _ptr(k["octree"]),
+            _ptr(k["blocks"]), _ptr(k["quads"]), _ptr(k["aabbs"]), _ptr(k["wbvh"]), _ptr(k["abvh"]),
+            _ptr(k["trigs"]), _ptr(k["atlas"]), W, H, L, _ptr(k["mats"]), _ptr(k["sky"]),
+            k["sky"].shape[1], k["sky"].shape[0], float(sc.sky_intensity), _ptr(k["sun"]),
+            int(sc.width), int(sc.height))
+        self.width, self.height = int(sc.width), int(sc.height)
+
+
+class _Lib:
+    prefix = ""
+
+    def __init__(self, path: str):
+        self.path = path
+        self.lib = C.CDLL(path)
+        p = self.prefix
+        f = getattr(self.lib, p + "_render_passes")
+        f.argtypes = [C.POINTER(OracleScene), C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                      C.c_void_p, C.c_int]
+        f.restype = C.c_int
+        f = getattr(self.lib, p + "_preview")
+        f.argtypes = [C.POINTER(OracleScene), C.c_void_p, C.c_int]
+        f.restype = C.c_int
+        f = getattr(self.lib, p + "_trace_records")
+        f.argtypes = [C.POINTER(OracleScene), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
+        f = getattr(self.lib, p + "_math")
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = None
+
+    def render_passes(self, sc, seeds, first_spp: int = 0, res: Optional[np.ndarray] = None,
+                      gid_range=None, threads: int = 8) -> np.ndarray:
+        """res[3*W*H] running mean after the given passes (rayTracer.cl:109-112)."""
+        h = sc if isinstance(sc, SceneHandle) else SceneHandle(sc)
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        n = h.width * h.height
+        if res is None:
+            res = np.zeros(3 * n, np.float32)
+        b, e = gid_range if gid_range is not None else (0, n)
+        getattr(self.lib, self.prefix + "_render_passes")(
+            C.byref(h.struct), _ptr(seeds), len(seeds), first_spp, b, e, _ptr(res), threads)
+        return res
+
+    def preview(self, sc, threads: int = 8) -> np.ndarray:
+        h = sc if isinstance(sc, SceneHandle) else SceneHandle(sc)
+        out = np.zeros(h.width * h.height, np.int32)
+        getattr(self.lib, self.prefix + "_preview")(C.byref(h.struct), _ptr(out), threads)
+        return out
+
+    def trace_records(self, sc, seed: int, gid: int):
+        h = sc if isinstance(sc, SceneHandle) else SceneHandle(sc)
+        hits = np.zeros(MAX_TRACES, HIT_DTYPE)
+        rad = np.zeros(3, np.float32)
+        n = getattr(self.lib, self.prefix + "_trace_records")(
+            C.byref(h.struct), int(seed), int(gid), _ptr(hits), _ptr(rad))
+        return hits[:n], rad
+
+    def math(self, which: int, a, b=None) -> np.ndarray:
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(a if b is None else b, np.float32)
+        out = np.empty_like(a)
+        getattr(self.lib, self.prefix + "_math")(which, a.size, _ptr(a), _ptr(b), _ptr(out))
+        return out
+
+
+class RefLib(_Lib):
+    prefix = "ref"
+
+    def __init__(self, path):
+        super().__init__(path)
+        self.lib.ref_pcg_stream.argtypes = [C.c_uint, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.ref_sun_basis.argtypes = [C.c_void_p, C.c_void_p]
+
+    def pcg_stream(self, state: int, n: int):
+        s = np.zeros(n, np.uint32)
+        f = np.zeros(n, np.float32)
+        self.lib.ref_pcg_stream(state, n, _ptr(s), _ptr(f))
+        return s, f
+
+    def sun_basis(self, sun: np.ndarray) -> np.ndarray:
+        sun = np.ascontiguousarray(sun, np.int32)
+        out = np.zeros(9, np.float32)
+        self.lib.ref_sun_basis(_ptr(sun), _ptr(out))
+        return out
+
+
+class PortLib(_Lib):
+    prefix = "port"
+
+    def __init__(self, path):
+        super().__init__(path)
+        self.lib.port_counters_reset.restype = None
+        self.lib.port_counters_read.argtypes = [C.c_void_p]
+        self.lib.port_counters_enable.argtypes = [C.c_int]
+
+    def counters(self, enable: Optional[bool] = None, reset: bool = False) -> dict:
+        if enable is not None:
+            self.lib.port_counters_enable(1 if enable else 0)
+        out = np.zeros(len(COUNTER_NAMES), np.int64)
+        self.lib.port_counters_read(_ptr(out))
+        if reset:
+            self.lib.port_counters_reset()
+        return dict(zip(COUNTER_NAMES, (int(v) for v in out)))
+
+
+def algorithmic_bytes(c: dict) -> float:
+    """algorithmic bytes of the reference access stream, per sample."""
+    total = (4 * c["node"] + 8 * c["block"] + 4 * c["model_hdr"] + 52 * c["aabb"] + 60 * c["quad"]
+             + 24 * c["mat"] + 4 * c["texel"] + 56 * c["bvh_inner"] + 4 * c["leaf_hdr"] + 80 * c["tri"]
+             + 16 * c["sky"] + 24 * c["samples"])
+    return total / max(c["samples"], 1)
+
+
+_ref: Optional[RefLib] = None
+_port: Optional[PortLib] = None
+
+
+def _make(target: str) -> None:
+    subprocess.run(["make", "-C", HERE, target], check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.PIPE)
+
+
+def ref(build: bool = True) -> Optional[RefLib]:
+    """The reference-kernel oracle, or None where it cannot exist (no /root/reference and no
+    prebuilt .so)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(HERE, "_ref", "libchunky_ref.so")
+        if build and os.path.isdir("/root/reference"):
+            _make("ref")
+        if not os.path.exists(path):
+            return None
+        _ref = RefLib(path)
+    return _ref
+
+
+def port(build: bool = True) -> PortLib:
+    global _port
+    if _port is None:
+        path = os.path.join(HERE, "libchunky_port.so")
+        if build:
+            _make("port")
+        _port = PortLib(path)
+    return _port

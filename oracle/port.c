@@ -1,0 +1,769 @@
+/* port.c — plain-C restatement of the reference's per-sample path (CPU oracle, "port" kind).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Used by tests/ as the checker, by __graft_entry__.smoke() and by
+ * bench.py's cpu_baseline leg.  Never linked into or called from chunkyclplugin_amd/.
+ *
+ * Pinning: this file is validated bit-for-bit against oracle/_ref (the reference kernel itself,
+ * compiled in place for x86-64) by tests/test_oracle_pinning.py in the build container, and
+ * against the committed outputs of that reference build under tests/golden/ everywhere else.
+ *
+ * Every function cites the reference lines it follows; K/ = /root/reference/src/main/opencl/
+ * kernel/include/.  Arithmetic contract: IEEE binary32 (binary64 at the reference's double
+ * literal sites), one rounding per source-level operation (-ffp-contract=off), OpenCL builtins
+ * as defined in chunkyclplugin_amd/csrc/rt_math.h.
+ *
+ * It also counts the reference algorithm's access stream (BASELINE.md section 4 "algorithmic
+ * bytes per sample"), which the roofline figure in bench.py is computed from.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../chunkyclplugin_amd/csrc/rt_math.h"
+#include "oracle_scene.h"
+
+#define EPS 0.000005f   /* K/constants.h:4 */
+#define OFFSET 0.0001f  /* K/constants.h:5 */
+#define ANY_TYPE 0x7FFFFFFE
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 add3(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul3(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 scale3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline float dot3(v3 a, v3 b) { return rt_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
+static inline v3 cross3(v3 a, v3 b) {
+    return V3(rt_cross_c(a.y, b.z, a.z, b.y), rt_cross_c(a.z, b.x, a.x, b.z), rt_cross_c(a.x, b.y, a.y, b.x));
+}
+static inline v3 normalize3(v3 a) { return scale3(a, rt_rlen3(a.x, a.y, a.z)); }
+
+/* ---------------------------------------------------------------- access-stream counters --- */
+typedef struct {
+    int64_t samples, traces, steps, node, block, model_hdr, aabb, quad, mat, texel, bvh_inner,
+        leaf_hdr, tri, sky, hits;
+} Counters;
+#define N_COUNTERS 15
+static Counters g_total;
+static int g_count_enabled = 0;
+static _Thread_local Counters* t_ctr = 0;
+#define COUNT(field, n) do { if (t_ctr) t_ctr->field += (n); } while (0)
+
+void port_counters_enable(int on) { g_count_enabled = on; }
+void port_counters_reset(void) { memset(&g_total, 0, sizeof g_total); }
+void port_counters_read(int64_t* out) { memcpy(out, &g_total, sizeof g_total); }
+static void counters_merge(const Counters* c) {
+    const int64_t* s = (const int64_t*)c;
+    int64_t* d = (int64_t*)&g_total;
+    for (int i = 0; i < N_COUNTERS; i++) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        d[i] += s[i];
+    }
+}
+
+/* ------------------------------------------------------------------------- path state ------ */
+/* K/wavefront.h:6-51 — Pixel, Ray and IntersectionRecord flattened; `ray` is shared between a
+ * record and its shadow copy exactly like the reference's Ray* aliasing (wavefront.h:66). */
+typedef struct {
+    v3 color, throughput;        /* Pixel */
+    v3 origin, direction;        /* Ray */
+    int ray_material, ray_depth; /* Ray.material stays 0 (wavefront.h:34) */
+} Path;
+typedef struct {
+    float distance;
+    int material;
+    v3 normal, point;
+    v4 color;
+    float emittance;
+} Record;
+
+typedef struct { /* K/sky.h:9-17 */
+    int flags, texture_size, texture;
+    float intensity;
+    v3 su, sv, sw;
+} Sun;
+
+/* ------------------------------------------------------------------------- primitives ------ */
+typedef struct { float xmin, xmax, ymin, ymax, zmin, zmax; } Box;
+
+/* K/primitives.h:30-48 */
+static float box_quick(const Box* b, v3 o, v3 inv) {
+    float t1x = (b->xmin - o.x) * inv.x, t1y = (b->ymin - o.y) * inv.y, t1z = (b->zmin - o.z) * inv.z;
+    float t2x = (b->xmax - o.x) * inv.x, t2y = (b->ymax - o.y) * inv.y, t2z = (b->zmax - o.z) * inv.z;
+    float tmin = rt_fmax(rt_fmin(t1x, t2x), rt_fmax(rt_fmin(t1y, t2y), rt_fmin(t1z, t2z)));
+    float tmax = rt_fmin(rt_fmax(t1x, t2x), rt_fmin(rt_fmax(t1y, t2y), rt_fmax(t1z, t2z)));
+    return (tmax < tmin) ? rt_nan() : tmin;
+}
+
+/* K/primitives.h:52-61 */
+static float box_exit(const Box* b, v3 o, v3 inv) {
+    float t1x = (b->xmin - o.x) * inv.x, t1y = (b->ymin - o.y) * inv.y, t1z = (b->zmin - o.z) * inv.z;
+    float t2x = (b->xmax - o.x) * inv.x, t2y = (b->ymax - o.y) * inv.y, t2z = (b->zmax - o.z) * inv.z;
+    return rt_fmin(rt_fmax(t1x, t2x), rt_fmin(rt_fmax(t1y, t2y), rt_fmax(t1z, t2z)));
+}
+
+/* K/primitives.h:66-112 (unit = 0) and :117-162 (map2 = 1).  Entry face by the exact-equality
+ * chain, last match wins.  `dir` is whatever the caller passes (block.h:52 passes the march
+ * position, Appendix B#1). */
+static float box_full(const Box* b, v3 o, v3 dir, v3 inv, v3* normal, float* u, float* v, int map2) {
+    float t1x = (b->xmin - o.x) * inv.x, t1y = (b->ymin - o.y) * inv.y, t1z = (b->zmin - o.z) * inv.z;
+    float t2x = (b->xmax - o.x) * inv.x, t2y = (b->ymax - o.y) * inv.y, t2z = (b->zmax - o.z) * inv.z;
+    float tmin = rt_fmax(rt_fmin(t1x, t2x), rt_fmax(rt_fmin(t1y, t2y), rt_fmin(t1z, t2z)));
+    float tmax = rt_fmin(rt_fmax(t1x, t2x), rt_fmin(rt_fmax(t1y, t2y), rt_fmax(t1z, t2z)));
+    if (tmax < tmin) return rt_nan();
+    v3 p = add3(o, scale3(dir, tmin)); /* origin + tmin * dir */
+    if (!map2) {
+        float dx = 1 / (b->xmax - b->xmin), dy = 1 / (b->ymax - b->ymin), dz = 1 / (b->zmax - b->zmin);
+        if (t1x == tmin) { *u = 1 - (p.z - b->zmin) * dz; *v = (p.y - b->ymin) * dy; *normal = V3(-1, 0, 0); }
+        if (t2x == tmin) { *u = (p.z - b->zmin) * dz; *v = (p.y - b->ymin) * dy; *normal = V3(1, 0, 0); }
+        if (t1y == tmin) { *u = (p.x - b->xmin) * dx; *v = 1 - (p.z - b->zmin) * dz; *normal = V3(0, -1, 0); }
+        if (t2y == tmin) { *u = (p.x - b->xmin) * dx; *v = (p.z - b->zmin) * dz; *normal = V3(0, 1, 0); }
+        if (t1z == tmin) { *u = (p.x - b->xmin) * dx; *v = (p.y - b->ymin) * dy; *normal = V3(0, 0, -1); }
+        if (t2z == tmin) { *u = 1 - (p.x - b->xmin) * dx; *v = (p.y - b->ymin) * dy; *normal = V3(0, 0, 1); }
+    } else {
+        if (t1x == tmin) { *u = p.z; *v = p.y; *normal = V3(-1, 0, 0); }
+        if (t2x == tmin) { *u = 1 - p.z; *v = p.y; *normal = V3(1, 0, 0); }
+        if (t1y == tmin) { *u = p.x; *v = p.z; *normal = V3(0, -1, 0); }
+        if (t2y == tmin) { *u = p.x; *v = 1 - p.z; *normal = V3(0, 1, 0); }
+        if (t1z == tmin) { *u = 1 - p.x; *v = p.y; *normal = V3(0, 0, -1); }
+        if (t2z == tmin) { *u = p.x; *v = p.y; *normal = V3(0, 0, 1); }
+    }
+    return tmin;
+}
+
+/* ------------------------------------------------------------------ atlas + materials ------ */
+static inline v4 scale4(v4 a, float s) { v4 r = {a.x * s, a.y * s, a.z * s, a.w * s}; return r; }
+static inline v4 mul4(v4 a, v4 b) { v4 r = {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; return r; }
+
+/* K/utils.h:6-14 — note /256 */
+static v4 color_from_argb(unsigned argb) {
+    v4 c;
+    c.w = (float)((argb >> 24) & 0xFF) / 256.0f;
+    c.x = (float)((argb >> 16) & 0xFF) / 256.0f;
+    c.y = (float)((argb >> 8) & 0xFF) / 256.0f;
+    c.z = (float)(argb & 0xFF) / 256.0f;
+    return c;
+}
+
+/* K/textureAtlas.h:10-28 + the image-array read contract of rt_math.h */
+static v4 atlas_read_uv(const OracleScene* s, float u, float v, int location, int size) {
+    int width = (size >> 16) & 0xFFFF, height = size & 0xFFFF;
+    v = 1 - v;
+    int x = rt_clampi((int)((u - EPS) * width), 0, width - 1);
+    int y = rt_clampi((int)((v - EPS) * height), 0, height - 1);
+    x += ((location >> 22) & 0x1FF) * 16;
+    y += ((location >> 13) & 0x1FF) * 16;
+    int d = location & 0x7FFFF;
+    x = rt_clampi(x, 0, s->atlas_w - 1);
+    y = rt_clampi(y, 0, s->atlas_h - 1);
+    d = rt_clampi(d, 0, s->atlas_layers - 1);
+    const uint8_t* t = s->atlas + 4 * (((size_t)d * s->atlas_h + y) * s->atlas_w + x);
+    COUNT(texel, 1);
+    v4 c = {rt_unorm8(t[0]), rt_unorm8(t[1]), rt_unorm8(t[2]), rt_unorm8(t[3])};
+    return c;
+}
+
+/* K/material.h:31-40 + :42-82 */
+static int material_sample(const OracleScene* s, int material, Record* rec, float u, float v) {
+    const int32_t* m = s->material_palette + material;
+    unsigned flags = m[0], tint = m[1], tex_size = m[2], color_w = m[3], ne = m[4];
+    COUNT(mat, 1);
+    v4 color = (flags & 4) ? atlas_read_uv(s, u, v, (int)color_w, (int)tex_size) : color_from_argb(color_w);
+    if (!(color.w > EPS)) return 0;
+    rec->color = color;
+    switch (tint >> 24) {
+        case 0xFF: rec->color = mul4(rec->color, color_from_argb(tint)); break;
+        case 1: rec->color = mul4(rec->color, color_from_argb(0xFF71A74Du)); break;
+        case 2: rec->color = mul4(rec->color, color_from_argb(0xFF8EB971u)); break;
+        case 3: rec->color = mul4(rec->color, color_from_argb(0xFF3F76E4u)); break;
+        default: break;
+    }
+    if (flags & 2)
+        rec->emittance = atlas_read_uv(s, u, v, (int)ne, (int)tex_size).w;
+    else
+        rec->emittance = (float)((ne & 0xFF) / 255.0); /* double site, material.h:79 */
+    return 1;
+}
+
+/* ------------------------------------------------------------------------ block models ----- */
+/* K/primitives.h:200-260.  +z faces leave `mat` unset in the reference (primitives.h:209-234,
+ * SURVEY.md Appendix B#9).  LLVM resolves that undef to the EAST material (the dead first store
+ * to `mat` is removed, then select(x==1, me, undef) folds to me) — observed in oracle/_ref at -O2
+ * and pinned by tests/test_oracle_pinning.py::test_aabb_plus_z_face — so +z = east material,
+ * flags 0 is the definition used here and in the HIP kernels. */
+static float textured_box(const int32_t* model, float best, v3 o, v3 dir, v3 inv, v3* normal, float* u,
+                          float* v, int* material) {
+    Box b;
+    memcpy(&b, model, 24);
+    int flags_all = model[6];
+    v3 n;
+    float tu, tv;
+    float dist = box_full(&b, o, dir, inv, &n, &tu, &tv, 1);
+    if (rt_isnan(dist) || dist >= best || dist < -EPS) return rt_nan();
+    int mat = model[8], flags = 0;
+    if (n.z == -1) { mat = model[7]; flags = flags_all; }
+    if (n.x == 1) { mat = model[8]; flags = flags_all >> 4; }
+    if (n.z == -1) { mat = model[9]; flags = flags_all >> 8; }
+    if (n.x == -1) { mat = model[10]; flags = flags_all >> 12; }
+    if (n.y == 1) { mat = model[11]; flags = flags_all >> 16; }
+    if (n.y == -1) { mat = model[12]; flags = flags_all >> 20; }
+    if (flags & 8) return rt_nan();
+    if (flags & 4) tu = 1 - tu;
+    if (flags & 2) tv = 1 - tv;
+    if (flags & 1) { float t = tu; tu = tv; tv = t; }
+    *material = mat;
+    *normal = n;
+    *u = tu;
+    *v = tv;
+    return dist;
+}
+
+/* K/primitives.h:274-319 */
+static float quad_hit(const int32_t* q, float best, v3 o, v3 dir, v3* normal, float* u, float* v) {
+    float f[13];
+    memcpy(f, q, sizeof f);
+    v3 qo = V3(f[0], f[1], f[2]), xv = V3(f[3], f[4], f[5]), yv = V3(f[6], f[7], f[8]);
+    v3 n = normalize3(cross3(xv, yv));
+    float denom = dot3(dir, n);
+    if (denom < -EPS) {
+        float t = -(dot3(o, n) - dot3(n, qo)) / denom;
+        if (t > -EPS && t < best) {
+            v3 pt = sub3(add3(o, scale3(dir, t)), qo);
+            float uu = dot3(pt, xv) / dot3(xv, xv);
+            float vv = dot3(pt, yv) / dot3(yv, yv);
+            if (uu >= 0 && uu <= 1 && vv >= 0 && vv <= 1) {
+                *u = f[9] + (uu * f[10]);
+                *v = f[11] + (vv * f[12]);
+                *normal = n;
+                return t;
+            }
+        }
+    }
+    return rt_nan();
+}
+
+/* K/block.h:30-118 */
+static float intersect_block(const OracleScene* s, int block, int bx, int by, int bz, Record* rec, v3 pos,
+                             v3 dir, v3 inv) {
+    if (block == ANY_TYPE) return rt_nan();
+    int type = s->block_palette[block], ptr = s->block_palette[block + 1];
+    COUNT(block, 1);
+    v3 no = sub3(sub3(pos, scale3(dir, OFFSET)), V3((float)bx, (float)by, (float)bz));
+    v3 normal = V3(0, 0, 0);
+    float u = 0, v = 0;
+    switch (type) {
+        case 1: {
+            Box unit = {0, 1, 0, 1, 0, 1};
+            float dist = box_full(&unit, no, pos, inv, &normal, &u, &v, 0); /* dir := pos, block.h:52 */
+            if (rt_isnan(dist)) return rt_nan();
+            rec->normal = normal;
+            return material_sample(s, ptr, rec, u, v) ? dist - OFFSET : rt_nan();
+        }
+        case 2: {
+            int hit = 0, material = 0;
+            float dist = rt_inf();
+            int boxes = s->aabb_models[ptr];
+            COUNT(model_hdr, 1);
+            for (int i = 0; i < boxes; i++) {
+                COUNT(aabb, 1);
+                float t = textured_box(s->aabb_models + ptr + 1 + i * 13, dist, no, dir, inv, &normal, &u, &v, &material);
+                if (!rt_isnan(t) && material_sample(s, material, rec, u, v)) {
+                    rec->normal = normal;
+                    dist = t;
+                    hit = 1;
+                }
+            }
+            return hit ? dist : rt_nan();
+        }
+        case 3: {
+            int hit = 0;
+            float dist = rt_inf();
+            int quads = s->quad_models[ptr];
+            COUNT(model_hdr, 1);
+            for (int i = 0; i < quads; i++) {
+                const int32_t* q = s->quad_models + ptr + 1 + i * 15;
+                COUNT(quad, 1);
+                float t = quad_hit(q, dist, no, dir, &normal, &u, &v);
+                if (!rt_isnan(t) && material_sample(s, q[13], rec, u, v)) {
+                    rec->normal = normal;
+                    dist = t;
+                    hit = 1;
+                }
+            }
+            return hit ? dist : rt_nan();
+        }
+        default: return rt_nan();
+    }
+}
+
+/* --------------------------------------------------------------------------- octree -------- */
+static inline int ifloor(float x) { return (int)rt_floor(x); } /* K/utils.h:16-19 */
+
+/* K/octree.h:41-109 */
+static int octree_intersect(const OracleScene* s, const Path* p, Record* rec, int draw_depth) {
+    const int32_t* tree = s->octree;
+    int depth = s->octree_depth;
+    v3 o = p->origin, d = p->direction;
+    float dist_march = 0;
+    v3 inv = V3(1 / d.x, 1 / d.y, 1 / d.z);
+    v3 off = scale3(d, OFFSET);
+    int lx = ifloor(o.x) >> depth, ly = ifloor(o.y) >> depth, lz = ifloor(o.z) >> depth;
+    if ((lx != 0) | (ly != 0) | (lz != 0)) {
+        float size = (float)(1 << depth);
+        Box world = {0, size, 0, size, 0, size};
+        float dist = box_quick(&world, o, inv);
+        if (rt_isnan(dist) || dist < 0) return 0;
+        dist_march += dist + OFFSET;
+    }
+    for (int i = 0; i < draw_depth; i++) {
+        if (dist_march > rec->distance) return 0;
+        v3 pos = add3(o, scale3(d, dist_march));
+        v3 po = add3(pos, off);
+        int bx = ifloor(po.x), by = ifloor(po.y), bz = ifloor(po.z);
+        if (((bx >> depth) != 0) | ((by >> depth) != 0) | ((bz >> depth) != 0)) return 0;
+        COUNT(steps, 1);
+        int level = depth;
+        int data = tree[0];
+        COUNT(node, 1);
+        while (data > 0) {
+            level--;
+            data = tree[data + ((((bx >> level) & 1) << 2) | (((by >> level) & 1) << 1) | ((bz >> level) & 1))];
+            COUNT(node, 1);
+        }
+        data = -data;
+        lx = bx >> level; ly = by >> level; lz = bz >> level;
+        if (data != p->ray_material) {
+            float dist = intersect_block(s, data, bx, by, bz, rec, pos, d, inv);
+            if (!rt_isnan(dist)) {
+                rec->distance = dist_march + dist;
+                rec->material = data;
+                return 1;
+            }
+        }
+        Box leaf = {(float)(lx << level), (float)((lx + 1) << level), (float)(ly << level),
+                    (float)((ly + 1) << level), (float)(lz << level), (float)((lz + 1) << level)};
+        dist_march += box_exit(&leaf, po, inv) + OFFSET;
+    }
+    return 0;
+}
+
+/* ----------------------------------------------------------------------------- BVH --------- */
+/* K/primitives.h:335-409 */
+static float triangle_hit(const int32_t* t, float best, v3 o, v3 dir, v3* normal, float* u, float* v, int* material) {
+    float f[19];
+    memcpy(f, t + 1, sizeof f);
+    int flags = t[0];
+    v3 e1 = V3(f[0], f[1], f[2]), e2 = V3(f[3], f[4], f[5]), to = V3(f[6], f[7], f[8]);
+    v3 pvec = cross3(dir, e2);
+    float det = dot3(e1, pvec);
+    if ((flags >> 8) & 1) {
+        if (det > -EPS && det < EPS) return rt_nan();
+    } else if (det > -EPS) {
+        return rt_nan();
+    }
+    float recip = 1 / det;
+    v3 tvec = sub3(o, to);
+    float uu = dot3(tvec, pvec) * recip;
+    if (uu < 0 || uu > 1) return rt_nan();
+    v3 qvec = cross3(tvec, e1);
+    float vv = dot3(dir, qvec) * recip;
+    if (vv < 0 || (uu + vv) > 1) return rt_nan();
+    float tt = dot3(e2, qvec) * recip;
+    if (tt > EPS && tt < best) {
+        float w = 1 - uu - vv;
+        *u = f[12] * uu + f[14] * vv + f[16] * w;
+        *v = f[13] * uu + f[15] * vv + f[17] * w;
+        *normal = V3(f[9], f[10], f[11]);
+        *material = t[19];
+        return tt;
+    }
+    return rt_nan();
+}
+
+static inline float as_f(int32_t i) { return rt_u2f((unsigned)i); }
+
+/* K/bvh.h:22-113 */
+static int bvh_intersect(const OracleScene* s, const int32_t* bvh, const Path* p, Record* rec) {
+    if (bvh[0] == 0 && rt_isnan(as_f(bvh[1])) && rt_isnan(as_f(bvh[2])) && rt_isnan(as_f(bvh[3])) &&
+        rt_isnan(as_f(bvh[4])) && rt_isnan(as_f(bvh[5])) && rt_isnan(as_f(bvh[6])))
+        return 0;
+    const int32_t* trigs = s->bvh_trigs;
+    int hit = 0, to_visit = 0, cur = 0;
+    int stack[64];
+    v3 o = p->origin, d = p->direction;
+    v3 inv = V3(1 / d.x, 1 / d.y, 1 / d.z);
+    for (;;) {
+        int head = bvh[cur];
+        if (head <= 0) {
+            int prim = -head;
+            int n = trigs[prim];
+            COUNT(leaf_hdr, 1);
+            for (int i = 0; i < n; i++) {
+                v3 normal;
+                float u, v;
+                int material;
+                COUNT(tri, 1);
+                float dist = triangle_hit(trigs + prim + 1 + 20 * i, rec->distance, o, d, &normal, &u, &v, &material);
+                if (!rt_isnan(dist) && material_sample(s, material, rec, u, v)) {
+                    rec->normal = normal;
+                    rec->distance = dist;
+                    hit = 1;
+                }
+            }
+            if (to_visit == 0) break;
+            cur = stack[--to_visit];
+        } else {
+            int second = head;
+            Box b1, b2;
+            memcpy(&b1, bvh + cur + 7 + 1, 24);
+            memcpy(&b2, bvh + second + 1, 24);
+            COUNT(bvh_inner, 1);
+            float t1 = box_quick(&b1, o, inv);
+            float t2 = box_quick(&b2, o, inv);
+            int miss1 = rt_isnan(t1) || t1 > rec->distance;
+            int miss2 = rt_isnan(t2) || t2 > rec->distance;
+            if (miss1) {
+                if (miss2) {
+                    if (to_visit == 0) break;
+                    cur = stack[--to_visit];
+                } else {
+                    cur = second;
+                }
+            } else if (miss2) {
+                cur += 7;
+            } else if (t1 < t2) {
+                stack[to_visit++] = second;
+                cur += 7;
+            } else {
+                stack[to_visit++] = cur + 7;
+                cur = second;
+            }
+        }
+    }
+    return hit;
+}
+
+/* K/kernel.h:14-24 */
+static int closest_intersect(const OracleScene* s, const Path* p, Record* rec, int draw_depth) {
+    COUNT(traces, 1);
+    int hit = 0;
+    hit |= octree_intersect(s, p, rec, draw_depth);
+    hit |= bvh_intersect(s, s->world_bvh, p, rec);
+    hit |= bvh_intersect(s, s->actor_bvh, p, rec);
+    if (hit) rec->point = add3(p->origin, scale3(p->direction, rec->distance - OFFSET));
+    return hit;
+}
+
+/* ----------------------------------------------------------------------- sun and sky ------- */
+/* K/sky.h:19-40 */
+static Sun sun_new(const int32_t* data) {
+    Sun sun;
+    sun.flags = data[0];
+    sun.texture_size = data[1];
+    sun.texture = data[2];
+    sun.intensity = as_f(data[3]);
+    float phi = as_f(data[4]), theta = as_f(data[5]);
+    float r = rt_fabs(rt_cos(phi));
+    sun.sw = V3(rt_cos(theta) * r, rt_sin(phi), rt_sin(theta) * r);
+    sun.su = (rt_fabs(sun.sw.x) > 0.1f) ? V3(0, 1, 0) : V3(1, 0, 0);
+    sun.sv = normalize3(cross3(sun.sw, sun.su));
+    sun.su = cross3(sun.sv, sun.sw);
+    return sun;
+}
+
+/* K/sky.h:97-106 + the linear / mirrored-repeat sampler contract of rt_math.h */
+static void sky_intersect(const OracleScene* s, const Path* p, Record* rec) {
+    v3 d = p->direction;
+    float theta = rt_atan2(d.z, d.x);
+    theta /= RT_PI_F * 2;
+    theta = rt_fmod1(rt_fmod1(theta) + 1);
+    float phi = (rt_asin(rt_clamp(d.y, -1.0f, 1.0f)) + RT_PI_2_F) * RT_1_PI_F;
+    int i0, i1, j0, j1;
+    float a, b;
+    rt_mirror_linear(theta, s->sky_w, &i0, &i1, &a);
+    rt_mirror_linear(phi, s->sky_h, &j0, &j1, &b);
+    const uint8_t* t00 = s->sky + 4 * ((size_t)j0 * s->sky_w + i0);
+    const uint8_t* t10 = s->sky + 4 * ((size_t)j0 * s->sky_w + i1);
+    const uint8_t* t01 = s->sky + 4 * ((size_t)j1 * s->sky_w + i0);
+    const uint8_t* t11 = s->sky + 4 * ((size_t)j1 * s->sky_w + i1);
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float c[4];
+    for (int k = 0; k < 4; k++)
+        c[k] = w00 * rt_unorm8(t00[k]) + w10 * rt_unorm8(t10[k]) + w01 * rt_unorm8(t01[k]) + w11 * rt_unorm8(t11[k]);
+    COUNT(sky, 1);
+    rec->color.x = c[0] * s->sky_intensity;
+    rec->color.y = c[1] * s->sky_intensity;
+    rec->color.z = c[2] * s->sky_intensity;
+    rec->color.w = c[3] * s->sky_intensity;
+}
+
+/* K/sky.h:42-66 */
+static void sun_intersect(const OracleScene* s, const Sun* sun, const Path* p, Record* rec) {
+    v3 d = p->direction;
+    if (!(sun->flags & 1) || dot3(d, sun->sw) < 0.5f) return;
+    float radius = 0.03f; /* `float radius = 0.03;` */
+    float width = radius * 4;
+    float width2 = width * 2;
+    float a = RT_PI_2_F - rt_acos(dot3(d, sun->su)) + width;
+    if (a >= 0 && a < width2) {
+        float b = RT_PI_2_F - rt_acos(dot3(d, sun->sv)) + width;
+        if (b >= 0 && b < width2) {
+            v4 c = atlas_read_uv(s, a / width2, b / width2, sun->texture, sun->texture_size);
+            c = scale4(c, sun->intensity);
+            rec->color.x += c.x; rec->color.y += c.y; rec->color.z += c.z; rec->color.w += c.w;
+        }
+    }
+}
+
+/* K/sky.h:68-93 — note direction = u * v (component-wise), then += w */
+static int sun_sample_direction(const Sun* sun, Path* p, Record* rec, unsigned* state) {
+    if (!(sun->flags & 1)) return 0;
+    float radius_cos = rt_cos(0.03f);
+    float x1 = rt_pcg_float(state), x2 = rt_pcg_float(state);
+    float cos_a = 1 - x1 + x1 * radius_cos;
+    float sin_a = rt_sqrt(1 - cos_a * cos_a);
+    float phi = 2 * RT_PI_F * x2;
+    float sp, cp;
+    rt_sincos(phi, &sp, &cp);
+    v3 u = scale3(sun->su, cp * sin_a);
+    v3 v = scale3(sun->sv, sp * sin_a);
+    v3 w = scale3(sun->sw, cos_a);
+    v3 dir = mul3(u, v);
+    dir = add3(dir, w);
+    dir = normalize3(dir);
+    p->direction = dir;
+    rec->emittance = rt_fabs(dot3(dir, rec->normal));
+    return 1;
+}
+
+/* K/kernel.h:26-31 */
+static void intersect_sky(const OracleScene* s, const Sun* sun, Path* p, Record* rec) {
+    sky_intersect(s, p, rec);
+    sun_intersect(s, sun, p, rec);
+    v3 c = V3(rec->color.x, rec->color.y, rec->color.z);
+    p->color = add3(p->color, scale3(mul3(c, p->throughput), rec->emittance));
+}
+
+/* K/kernel.h:33-44 */
+static void apply_ray_color(Path* p, Record* rec, float emitter_scale) {
+    p->origin = rec->point;
+    v3 c = V3(rec->color.x, rec->color.y, rec->color.z);
+    p->throughput = mul3(p->throughput, c);
+    v3 e = scale3(c, rec->emittance * emitter_scale);
+    p->color = add3(p->color, mul3(e, p->throughput));
+}
+
+/* K/kernel.h:46-98 */
+static int next_path(Path* p, Record* rec, unsigned* state, int max_depth) {
+    p->origin = rec->point;
+    float x1 = rt_pcg_float(state), x2 = rt_pcg_float(state);
+    float r = rt_sqrt(x1);
+    float theta = 2 * RT_PI_F * x2;
+    float st, ct;
+    rt_sincos(theta, &st, &ct);
+    float tx = r * ct, ty = r * st, tz = rt_sqrt(1 - x1);
+    v3 n = rec->normal;
+    float xx, xy, xz = 0;
+    if ((double)rt_fabs(n.x) > 0.1) { xx = 0; xy = 1; } else { xx = 1; xy = 0; } /* double compare, kernel.h:66 */
+    float ux = xy * n.z - xz * n.y;
+    float uy = xz * n.x - xx * n.z;
+    float uz = xx * n.y - xy * n.x;
+    r = 1 / rt_sqrt(ux * ux + uy * uy + uz * uz);
+    ux *= r; uy *= r; uz *= r;
+    float vx = uy * n.z - uz * n.y;
+    float vy = uz * n.x - ux * n.z;
+    float vz = ux * n.y - uy * n.x;
+    p->direction.x = ux * tx + vx * ty + n.x * tz;
+    p->direction.y = uy * tx + vy * ty + n.y * tz;
+    p->direction.z = uz * tx + vz * ty + n.z * tz;
+    p->origin = add3(p->origin, scale3(p->direction, OFFSET));
+    p->ray_depth += 1;
+    rec->distance = rt_inf();
+    return p->ray_depth < max_depth;
+}
+
+/* ------------------------------------------------------------------------- camera ---------- */
+/* K/rayTracer.cl:55-91 + K/camera.h:8-32.  `normalize_dir` is the preview kernel's extra
+ * normalize (rayTracer.cl:186). */
+static void primary_ray(const OracleScene* s, int gid, unsigned* state, Path* p, int normalize_dir) {
+    if (s->projector_type != -1) {
+        const float* cs = s->camera_settings;
+        float half_width = (float)(s->width / (2.0 * s->height));
+        float inv_height = (float)(1.0 / s->height);
+        float x = -half_width + ((float)(gid % s->width) + rt_pcg_float(state)) * inv_height;
+        float y = (float)(-0.5 + (double)(((float)(gid / s->width) + rt_pcg_float(state)) * inv_height));
+        float aperture = cs[12], subject = cs[13], fov_tan = cs[14];
+        v3 o = V3(0, 0, 0);
+        v3 d = V3(fov_tan * x, fov_tan * y, 1.0f);
+        if (aperture > 0) {
+            d = scale3(d, subject / d.z);
+            float r = rt_sqrt(rt_pcg_float(state)) * aperture;
+            float theta = (float)((double)(rt_pcg_float(state) * RT_PI_F) * 2.0);
+            float st, ct;
+            rt_sincos(theta, &st, &ct);
+            float rx = ct * r, ry = st * r;
+            d = sub3(d, V3(rx, ry, 0));
+            o = add3(o, V3(rx, ry, 0));
+        }
+        if (normalize_dir) d = normalize3(d);
+        v3 m1 = V3(cs[3], cs[4], cs[5]), m2 = V3(cs[6], cs[7], cs[8]), m3 = V3(cs[9], cs[10], cs[11]);
+        p->direction = V3(dot3(m1, d), dot3(m2, d), dot3(m3, d));
+        p->origin = add3(V3(dot3(m1, o), dot3(m2, o), dot3(m3, o)), V3(cs[0], cs[1], cs[2]));
+    } else {
+        const float* r = s->camera_settings + (size_t)gid * 6;
+        p->origin = V3(r[0], r[1], r[2]);
+        p->direction = V3(r[3], r[4], r[5]);
+    }
+}
+
+static void path_init(Path* p, Record* rec) {
+    p->color = V3(0, 0, 0);
+    p->throughput = V3(1, 1, 1);
+    p->origin = V3(0, 0, 0);
+    p->direction = V3(0, 0, 0);
+    p->ray_material = 0;
+    p->ray_depth = 0;
+    memset(rec, 0, sizeof *rec);
+    rec->distance = rt_inf();
+}
+
+static void put_hit(OracleHit* h, int hit, const Record* r) {
+    h->hit = hit;
+    h->material = r->material;
+    h->distance = r->distance;
+    h->normal[0] = r->normal.x; h->normal[1] = r->normal.y; h->normal[2] = r->normal.z;
+    h->color[0] = r->color.x; h->color[1] = r->color.y; h->color[2] = r->color.z; h->color[3] = r->color.w;
+    h->emittance = r->emittance;
+    h->point[0] = r->point.x; h->point[1] = r->point.y; h->point[2] = r->point.z;
+}
+
+/* One sample: K/rayTracer.cl:40-107.  Returns pixel.color; optionally records each trace. */
+static v3 trace_sample(const OracleScene* s, const Sun* sun, int seed, int gid, OracleHit* hits, int* n_hits) {
+    Path p;
+    Record rec;
+    path_init(&p, &rec);
+    unsigned state = (unsigned)seed + (unsigned)gid;
+    rt_pcg_next(&state);
+    primary_ray(s, gid, &state, &p, 0);
+    int n = 0;
+    COUNT(samples, 1);
+    do {
+        int hit = closest_intersect(s, &p, &rec, 256);
+        if (hits) put_hit(&hits[n++], hit, &rec);
+        if (!hit) {
+            rec.emittance = 1;
+            intersect_sky(s, sun, &p, &rec);
+            break;
+        }
+        COUNT(hits, 1);
+        apply_ray_color(&p, &rec, 13.0f);
+        if (sun_sample_direction(sun, &p, &rec, &state)) {
+            Record shadow = rec; /* IntersectionRecord_copy, wavefront.h:64-78 */
+            shadow.point = rec.normal; /* the copy's dead `point = normal` (wavefront.h:73) */
+            int sh = closest_intersect(s, &p, &shadow, 256);
+            if (hits) put_hit(&hits[n++], sh, &shadow);
+            if (!sh) intersect_sky(s, sun, &p, &shadow);
+        }
+    } while (next_path(&p, &rec, &state, 5));
+    if (n_hits) *n_hits = n;
+    return p.color;
+}
+
+/* ------------------------------------------------------------------------ entry points ----- */
+/* Host pass loop of OpenClPathTracingRenderer.java:102-144 around the accumulate of
+ * K/rayTracer.cl:109-112: pass k uses seeds[k] and bufferSpp = first_spp + k. */
+int port_render_passes(const OracleScene* s, const int32_t* seeds, int n_passes, int first_spp,
+                       int64_t gid_begin, int64_t gid_end, float* res, int threads) {
+    Sun sun = sun_new(s->sun);
+    if (threads < 1) threads = 1;
+    for (int k = 0; k < n_passes; k++) {
+        int seed = seeds[k], spp = first_spp + k;
+#pragma omp parallel num_threads(threads)
+        {
+            Counters local;
+            memset(&local, 0, sizeof local);
+            t_ctr = g_count_enabled ? &local : 0;
+#pragma omp for schedule(dynamic, 256)
+            for (int64_t gid = gid_begin; gid < gid_end; gid++) {
+                v3 c = trace_sample(s, &sun, seed, (int)gid, 0, 0);
+                float* px = res + 3 * gid;
+                px[0] = (px[0] * spp + c.x) / (spp + 1);
+                px[1] = (px[1] * spp + c.y) / (spp + 1);
+                px[2] = (px[2] * spp + c.z) / (spp + 1);
+            }
+            if (g_count_enabled) counters_merge(&local);
+            t_ctr = 0;
+        }
+    }
+    return 0;
+}
+
+int port_trace_records(const OracleScene* s, int seed, int gid, OracleHit* out, float* radiance) {
+    Sun sun = sun_new(s->sun);
+    int n = 0;
+    v3 c = trace_sample(s, &sun, seed, gid, out, &n);
+    radiance[0] = c.x; radiance[1] = c.y; radiance[2] = c.z;
+    return n;
+}
+
+/* K/rayTracer.cl:115-217 */
+int port_preview(const OracleScene* s, int32_t* argb, int threads) {
+    Sun sun = sun_new(s->sun);
+    int W = s->width, H = s->height;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads)
+    for (int gid = 0; gid < W * H; gid++) {
+        int px = gid % W, py = gid / W;
+        if ((px == W / 2 && (py >= H / 2 - 5 && py <= H / 2 + 5)) ||
+            (py == H / 2 && (px >= W / 2 - 5 && px <= W / 2 + 5))) {
+            argb[gid] = (int32_t)0xFFFFFFFFu;
+            continue;
+        }
+        Path p;
+        Record rec;
+        path_init(&p, &rec);
+        unsigned state = 0;
+        rt_pcg_next(&state);
+        primary_ray(s, gid, &state, &p, 1);
+        if (closest_intersect(s, &p, &rec, 256)) {
+            float shading = dot3(rec.normal, V3(0.25f, 0.866f, 0.433f));
+            shading = rt_fmax(0.3f, shading);
+            rec.color = scale4(rec.color, shading);
+        } else {
+            rec.emittance = 1;
+            intersect_sky(s, &sun, &p, &rec);
+        }
+        float r = rt_sqrt(rec.color.x), g = rt_sqrt(rec.color.y), b = rt_sqrt(rec.color.z);
+        int ri = ifloor(rt_clamp(r * 255.0f, 0.0f, 255.0f));
+        int gi = ifloor(rt_clamp(g * 255.0f, 0.0f, 255.0f));
+        int bi = ifloor(rt_clamp(b * 255.0f, 0.0f, 255.0f));
+        argb[gid] = (int32_t)(0xFF000000u | ((unsigned)ri << 16) | ((unsigned)gi << 8) | (unsigned)bi);
+    }
+    return 0;
+}
+
+void port_math(int which, int n, const float* a, const float* b, float* out) {
+    for (int i = 0; i < n; i++) {
+        switch (which) {
+            case 0: out[i] = rt_sin(a[i]); break;
+            case 1: out[i] = rt_cos(a[i]); break;
+            case 2: out[i] = rt_asin(a[i]); break;
+            case 3: out[i] = rt_acos(a[i]); break;
+            case 4: out[i] = rt_atan2(a[i], b[i]); break;
+            case 5: out[i] = rt_fmod1(a[i]); break;
+            case 6: out[i] = rt_fmin(a[i], b[i]); break;
+            case 7: out[i] = rt_fmax(a[i], b[i]); break;
+            case 8: out[i] = rt_sqrt(a[i]); break;
+            case 9: out[i] = a[i] / b[i]; break;
+            default: out[i] = 0;
+        }
+    }
+}
