@@ -1,0 +1,685 @@
+// capi.hip — implementation of include/chunky_hip.h: device context, scene upload, render target
+// and the host pass loop (the C++ counterpart of the reference's Java host side,
+// J/opencl/renderer/{RendererInstance,ClSceneLoader}.java and J/opencl/OpenClPathTracingRenderer.java).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/chunky_hip.h"
+#include "kernels.hpp"
+#include "rt_device.hpp"
+
+using namespace chunky;
+
+static_assert(sizeof(chunky_hit_record) == sizeof(HitRecord), "record layouts must agree");
+static_assert(CHUNKY_MAX_TRACES == kMaxTraces, "trace capacity must agree");
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local std::string tls_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tls_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(CHUNKY_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ context
+struct chunky_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::recursive_mutex mu;  // the reference's renderLock
+    std::string name;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t upload(const void* src, size_t n, hipStream_t s) {
+        if (n != bytes || !p) {
+            release();
+            hipError_t e = hipMalloc(&p, n ? n : 4);
+            if (e != hipSuccess) return e;
+            bytes = n;
+        }
+        if (n == 0) return hipMemsetAsync(p, 0, 4, s);
+        hipError_t e = hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(s);  // caller may reuse its array on return (COPY_HOST_PTR)
+    }
+};
+
+struct chunky_scene {
+    chunky_ctx* ctx = nullptr;
+    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky;
+    int octree_depth = -1;
+    int atlas_w = 0, atlas_h = 0, atlas_layers = 0;
+    int sky_w = 0, sky_h = 0;
+    float sky_intensity = 0;
+    int sun[6] = {0, 0, 0, 0, 0, 0};
+    bool have_sun = false, world_empty = true, actor_empty = true;
+    bool have_world = false, have_actor = false;
+    int refs = 1;  // owner + render targets
+};
+
+struct chunky_render {
+    chunky_ctx* ctx = nullptr;
+    chunky_scene* scene = nullptr;
+    int width = 0, height = 0;
+    CameraView cam{};
+    bool have_camera = false;
+    DevBuf rays;
+    RenderOpts opts{256, 5, 13.0f};
+    int kernel_variant = 0;
+    ShardView shard{0, 1, 256, 0};
+    DevBuf own_fb;
+    float* fb = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // timing brackets of enqueued launches
+    std::vector<hipEvent_t> free_events;
+    float timed_ms = 0;
+    int timed_launches = 0;
+    ~chunky_render() {
+        for (auto& p : pending) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        for (auto e : free_events) (void)hipEventDestroy(e);
+    }
+};
+
+static int n_local_slots(int n_pixels, const ShardView& t) {
+    if (t.world == 1) return n_pixels;
+    int n_tiles = (n_pixels + t.tile - 1) / t.tile;
+    int mine = (n_tiles - t.rank + t.world - 1) / t.world;  // tiles rank, rank+world, ...
+    return mine > 0 ? mine * t.tile : 0;
+}
+
+// ------------------------------------------------------------------------------------ device
+extern "C" const char* chunky_last_error(void) { return tls_error.c_str(); }
+extern "C" const char* chunky_version(void) { return "chunky-hip 0.1 gfx950"; }
+
+extern "C" int chunky_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int chunky_device_name(int device, char* buf, int buf_len) {
+    if (!buf || buf_len <= 0) return fail(CHUNKY_E_INVALID, "chunky_device_name: no buffer");
+    hipDeviceProp_t prop;
+    if (device < 0 || device >= chunky_device_count()) return fail(CHUNKY_E_NO_DEVICE, "no HIP device %d", device);
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_init(int device, chunky_ctx** out) {
+    if (!out) return fail(CHUNKY_E_INVALID, "chunky_init: out is NULL");
+    *out = nullptr;
+    int n = chunky_device_count();
+    if (n <= 0) return fail(CHUNKY_E_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(CHUNKY_E_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<chunky_ctx> c(new chunky_ctx);
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    char nm[256];
+    if (chunky_device_name(device, nm, sizeof nm) == CHUNKY_OK) c->name = nm;
+    *out = c.release();
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_shutdown(chunky_ctx* ctx) {
+    if (!ctx) return fail(CHUNKY_E_INVALID, "chunky_shutdown: NULL context");
+    {
+        std::lock_guard<std::recursive_mutex> g(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+    return CHUNKY_OK;
+}
+
+// ------------------------------------------------------------------------------------ scene
+#define LOCK_SCENE(s)                                                        \
+    if (!(s) || !(s)->ctx) return fail(CHUNKY_E_INVALID, "NULL scene");      \
+    std::lock_guard<std::recursive_mutex> guard_((s)->ctx->mu);              \
+    HIP_TRY(hipSetDevice((s)->ctx->device))
+
+extern "C" int chunky_scene_create(chunky_ctx* ctx, chunky_scene** out) {
+    if (!ctx || !out) return fail(CHUNKY_E_INVALID, "chunky_scene_create: NULL argument");
+    chunky_scene* s = new chunky_scene;
+    s->ctx = ctx;
+    *out = s;
+    return CHUNKY_OK;
+}
+
+static void scene_unref(chunky_scene* s) {
+    if (--s->refs == 0) delete s;
+}
+
+extern "C" int chunky_scene_destroy(chunky_scene* scene) {
+    LOCK_SCENE(scene);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    scene_unref(scene);
+    return CHUNKY_OK;
+}
+
+static int check_ints(const int32_t* p, int64_t n, const char* what) {
+    if (n < 0 || (n > 0 && !p)) return fail(CHUNKY_E_INVALID, "%s: bad array (n=%lld)", what, (long long)n);
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree, int64_t n, int depth) {
+    LOCK_SCENE(scene);
+    if (int rc = check_ints(tree, n, "set_octree")) return rc;
+    if (n < 1) return fail(CHUNKY_E_INVALID, "set_octree: empty tree");
+    if (depth < 0 || depth > 30) return fail(CHUNKY_E_INVALID, "set_octree: depth %d out of range", depth);
+    // every branch value must address a whole 8-int child group inside the array (K/octree.h:83-87)
+    for (int64_t i = 0; i < n; i++) {
+        int32_t v = tree[i];
+        if (v > 0 && (int64_t)v + 8 > n) return fail(CHUNKY_E_INVALID, "set_octree: node %lld points outside the tree", (long long)i);
+    }
+    HIP_TRY(scene->octree.upload(tree, (size_t)n * 4, scene->ctx->stream));
+    scene->octree_depth = depth;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_scene_load_octree(chunky_scene* scene, const int32_t* tree_data, int64_t n, int depth,
+                                        const int32_t* block_mapping, int64_t n_mapping) {
+    if (int rc = check_ints(tree_data, n, "load_octree")) return rc;
+    if (int rc = check_ints(block_mapping, n_mapping, "load_octree mapping")) return rc;
+    std::vector<int32_t> mapped((size_t)n);
+    for (int64_t i = 0; i < n; i++) {  // ClSceneLoader.java:56-58
+        int32_t v = tree_data[i];
+        mapped[(size_t)i] = (v > 0 || -(int64_t)v >= n_mapping) ? v : -block_mapping[-v];
+    }
+    return chunky_scene_set_octree(scene, mapped.data(), n, depth);
+}
+
+extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int32_t* data, int64_t n) {
+    LOCK_SCENE(scene);
+    if (int rc = check_ints(data, n, "set_palette")) return rc;
+    DevBuf* dst = nullptr;
+    switch (kind) {
+        case CHUNKY_PALETTE_BLOCK: dst = &scene->blocks; break;
+        case CHUNKY_PALETTE_MATERIAL: dst = &scene->materials; break;
+        case CHUNKY_PALETTE_AABB: dst = &scene->aabbs; break;
+        case CHUNKY_PALETTE_QUAD: dst = &scene->quads; break;
+        case CHUNKY_PALETTE_TRIG: dst = &scene->trigs; break;
+        default: return fail(CHUNKY_E_INVALID, "set_palette: unknown kind %d", kind);
+    }
+    HIP_TRY(dst->upload(data, (size_t)n * 4, scene->ctx->stream));
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_scene_set_bvh(chunky_scene* scene, int which, const int32_t* nodes, int64_t n) {
+    LOCK_SCENE(scene);
+    if (int rc = check_ints(nodes, n, "set_bvh")) return rc;
+    if (which != CHUNKY_BVH_WORLD && which != CHUNKY_BVH_ACTOR) return fail(CHUNKY_E_INVALID, "set_bvh: which=%d", which);
+    if (n < 7) return fail(CHUNKY_E_INVALID, "set_bvh: a BVH has at least one 7-int node (got %lld ints)", (long long)n);
+    bool empty = nodes[0] == 0;  // K/bvh.h:23-32
+    for (int k = 1; k <= 6 && empty; k++) {
+        float f;
+        memcpy(&f, &nodes[k], 4);
+        empty = f != f;
+    }
+    DevBuf& dst = which == CHUNKY_BVH_WORLD ? scene->world_bvh : scene->actor_bvh;
+    HIP_TRY(dst.upload(nodes, (size_t)n * 4, scene->ctx->stream));
+    if (which == CHUNKY_BVH_WORLD) {
+        scene->world_empty = empty;
+        scene->have_world = true;
+    } else {
+        scene->actor_empty = empty;
+        scene->have_actor = true;
+    }
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_scene_set_atlas(chunky_scene* scene, const uint8_t* rgba, int w, int h, int layers) {
+    LOCK_SCENE(scene);
+    if (w <= 0 || h <= 0 || layers <= 0) return fail(CHUNKY_E_INVALID, "set_atlas: bad size %dx%dx%d", w, h, layers);
+    size_t bytes = (size_t)w * h * layers * 4;
+    if (rgba) {
+        HIP_TRY(scene->atlas.upload(rgba, bytes, scene->ctx->stream));
+    } else {
+        scene->atlas.release();
+        HIP_TRY(hipMalloc(&scene->atlas.p, bytes));
+        scene->atlas.bytes = bytes;
+        HIP_TRY(hipMemsetAsync(scene->atlas.p, 0, bytes, scene->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(scene->ctx->stream));
+    }
+    scene->atlas_w = w;
+    scene->atlas_h = h;
+    scene->atlas_layers = layers;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_scene_write_atlas_tile(chunky_scene* scene, int x, int y, int layer, int w, int h,
+                                             const uint8_t* rgba) {
+    LOCK_SCENE(scene);
+    if (!scene->atlas.p) return fail(CHUNKY_E_STATE, "write_atlas_tile before set_atlas");
+    if (!rgba || x < 0 || y < 0 || layer < 0 || w <= 0 || h <= 0 || x + w > scene->atlas_w || y + h > scene->atlas_h ||
+        layer >= scene->atlas_layers)
+        return fail(CHUNKY_E_INVALID, "write_atlas_tile: region outside the atlas");
+    char* base = (char*)scene->atlas.p + (((size_t)layer * scene->atlas_h + y) * scene->atlas_w + x) * 4;
+    HIP_TRY(hipMemcpy2DAsync(base, (size_t)scene->atlas_w * 4, rgba, (size_t)w * 4, (size_t)w * 4, h,
+                             hipMemcpyHostToDevice, scene->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(scene->ctx->stream));
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_scene_set_sky(chunky_scene* scene, const uint8_t* rgba, int w, int h, float intensity) {
+    LOCK_SCENE(scene);
+    if (!rgba || w <= 0 || h <= 0) return fail(CHUNKY_E_INVALID, "set_sky: bad texture");
+    HIP_TRY(scene->sky.upload(rgba, (size_t)w * h * 4, scene->ctx->stream));
+    scene->sky_w = w;
+    scene->sky_h = h;
+    scene->sky_intensity = intensity;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_scene_set_sun(chunky_scene* scene, const int32_t sun[6]) {
+    LOCK_SCENE(scene);
+    if (!sun) return fail(CHUNKY_E_INVALID, "set_sun: NULL");
+    memcpy(scene->sun, sun, sizeof scene->sun);
+    scene->have_sun = true;
+    return CHUNKY_OK;
+}
+
+static float bits_to_float(int32_t i) {
+    float f;
+    memcpy(&f, &i, 4);
+    return f;
+}
+
+// Assemble the kernel-side view; Sun_new (K/sky.h:19-40) is evaluated here, on the host, with the
+// same rt_math.h the device uses.
+static int scene_view(const chunky_scene* s, SceneView* v) {
+    if (!s->octree.p || s->octree_depth < 0) return fail(CHUNKY_E_STATE, "scene has no octree");
+    if (!s->blocks.p || !s->materials.p) return fail(CHUNKY_E_STATE, "scene has no block/material palette");
+    if (!s->atlas.p) return fail(CHUNKY_E_STATE, "scene has no texture atlas");
+    if (!s->sky.p) return fail(CHUNKY_E_STATE, "scene has no sky texture");
+    if (!s->have_sun) return fail(CHUNKY_E_STATE, "scene has no sun");
+    if ((!s->world_empty || !s->actor_empty) && !s->trigs.p) return fail(CHUNKY_E_STATE, "scene has a BVH but no triangles");
+    v->octree = (const int*)s->octree.p;
+    v->blocks = (const int*)s->blocks.p;
+    v->quads = (const int*)s->quads.p;
+    v->aabbs = (const int*)s->aabbs.p;
+    v->world_bvh = (const int*)s->world_bvh.p;
+    v->actor_bvh = (const int*)s->actor_bvh.p;
+    v->trigs = (const int*)s->trigs.p;
+    v->atlas = (const uint32_t*)s->atlas.p;
+    v->materials = (const int*)s->materials.p;
+    v->sky = (const uint32_t*)s->sky.p;
+    v->octree_depth = s->octree_depth;
+    v->atlas_w = s->atlas_w;
+    v->atlas_h = s->atlas_h;
+    v->atlas_layers = s->atlas_layers;
+    v->sky_w = s->sky_w;
+    v->sky_h = s->sky_h;
+    v->sky_intensity = s->sky_intensity;
+    v->sun_flags = s->sun[0];
+    v->sun_tex_size = s->sun[1];
+    v->sun_tex = s->sun[2];
+    v->sun_intensity = bits_to_float(s->sun[3]);
+    float phi = bits_to_float(s->sun[4]), theta = bits_to_float(s->sun[5]);
+    float r = rt_fabs(rt_cos(phi));
+    float swx = rt_cos(theta) * r, swy = rt_sin(phi), swz = rt_sin(theta) * r;
+    float sux = 1, suy = 0, suz = 0;
+    if (rt_fabs(swx) > 0.1f) {
+        sux = 0;
+        suy = 1;
+    }
+    // sv = normalize(cross(sw, su)); su = cross(sv, sw)
+    float cx = rt_cross_c(swy, suz, swz, suy), cy = rt_cross_c(swz, sux, swx, suz), cz = rt_cross_c(swx, suy, swy, sux);
+    float rl = rt_rlen3(cx, cy, cz);
+    float svx = cx * rl, svy = cy * rl, svz = cz * rl;
+    v->sw = f3{swx, swy, swz};
+    v->sv = f3{svx, svy, svz};
+    v->su = f3{rt_cross_c(svy, swz, svz, swy), rt_cross_c(svz, swx, svx, swz), rt_cross_c(svx, swy, svy, swx)};
+    v->sun_radius_cos = rt_cos(0.03f);
+    v->world_bvh_empty = (s->world_empty || !s->world_bvh.p) ? 1 : 0;
+    v->actor_bvh_empty = (s->actor_empty || !s->actor_bvh.p) ? 1 : 0;
+    return CHUNKY_OK;
+}
+
+// ------------------------------------------------------------------------------------ render
+#define LOCK_RENDER(r)                                                       \
+    if (!(r) || !(r)->ctx) return fail(CHUNKY_E_INVALID, "NULL render");     \
+    std::lock_guard<std::recursive_mutex> guard_((r)->ctx->mu);              \
+    HIP_TRY(hipSetDevice((r)->ctx->device))
+
+extern "C" int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int width, int height, chunky_render** out) {
+    if (!ctx || !scene || !out) return fail(CHUNKY_E_INVALID, "chunky_render_create: NULL argument");
+    if (scene->ctx != ctx) return fail(CHUNKY_E_INVALID, "scene belongs to another context");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (1 << 30))
+        return fail(CHUNKY_E_INVALID, "bad image size %dx%d", width, height);
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::unique_ptr<chunky_render> r(new chunky_render);
+    r->ctx = ctx;
+    r->scene = scene;
+    r->width = width;
+    r->height = height;
+    size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    HIP_TRY(hipMalloc(&r->own_fb.p, bytes));
+    r->own_fb.bytes = bytes;
+    r->fb = (float*)r->own_fb.p;
+    HIP_TRY(hipMemsetAsync(r->fb, 0, bytes, ctx->stream));
+    r->shard = ShardView{0, 1, 256, width * height};
+    scene->refs++;
+    *out = r.release();
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_destroy(chunky_render* r) {
+    LOCK_RENDER(r);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    scene_unref(r->scene);
+    delete r;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_set_camera(chunky_render* r, int projector_type, const float* settings, int64_t n) {
+    LOCK_RENDER(r);
+    if (!settings) return fail(CHUNKY_E_INVALID, "set_camera: NULL settings");
+    CameraView& c = r->cam;
+    c.width = r->width;
+    c.height = r->height;
+    c.half_width = (float)(r->width / (2.0 * r->height));  // K/rayTracer.cl:66
+    c.inv_height = (float)(1.0 / r->height);               // K/rayTracer.cl:67
+    if (projector_type == 0) {
+        if (n != 15) return fail(CHUNKY_E_INVALID, "set_camera: pinhole needs 15 floats, got %lld", (long long)n);
+        memcpy(c.pos, settings, 12);
+        memcpy(c.m, settings + 3, 36);
+        c.aperture = settings[12];
+        c.subject_distance = settings[13];
+        c.fov_tan = settings[14];
+        c.rays = nullptr;
+    } else if (projector_type == -1) {
+        int64_t need = (int64_t)r->width * r->height * 6;
+        if (n != need) return fail(CHUNKY_E_INVALID, "set_camera: pre-generated rays need %lld floats, got %lld", (long long)need, (long long)n);
+        HIP_TRY(hipStreamSynchronize(r->ctx->stream));  // rays may still be read by queued passes
+        HIP_TRY(r->rays.upload(settings, (size_t)n * 4, r->ctx->stream));
+        c.rays = (const float*)r->rays.p;
+    } else {
+        return fail(CHUNKY_E_INVALID, "set_camera: projector type %d is not supported (0 or -1)", projector_type);
+    }
+    c.projector_type = projector_type;
+    r->have_camera = true;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_set_option(chunky_render* r, int option, int32_t value) {
+    LOCK_RENDER(r);
+    switch (option) {
+        case CHUNKY_OPT_DRAW_DEPTH:
+            if (value < 0) return fail(CHUNKY_E_INVALID, "draw depth must be >= 0");
+            r->opts.draw_depth = value;
+            break;
+        case CHUNKY_OPT_MAX_DEPTH:
+            if (value < 1 || value > 5) return fail(CHUNKY_E_INVALID, "max depth must be in 1..5");
+            r->opts.max_depth = value;
+            break;
+        case CHUNKY_OPT_EMITTER_SCALE: r->opts.emitter_scale = bits_to_float(value); break;
+        case CHUNKY_OPT_KERNEL: r->kernel_variant = value; break;
+        default: return fail(CHUNKY_E_INVALID, "unknown option %d", option);
+    }
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_set_shard(chunky_render* r, int rank, int world, int tile) {
+    LOCK_RENDER(r);
+    if (world < 1 || rank < 0 || rank >= world || tile < 1) return fail(CHUNKY_E_INVALID, "set_shard: rank %d / world %d / tile %d", rank, world, tile);
+    ShardView t{rank, world, tile, 0};
+    t.n_local = n_local_slots(r->width * r->height, t);
+    r->shard = t;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_set_device_buffer(chunky_render* r, void* device_ptr) {
+    LOCK_RENDER(r);
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    r->fb = device_ptr ? (float*)device_ptr : (float*)r->own_fb.p;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_device_buffer(chunky_render* r, void** device_ptr) {
+    LOCK_RENDER(r);
+    if (!device_ptr) return fail(CHUNKY_E_INVALID, "NULL out pointer");
+    *device_ptr = r->fb;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_reset(chunky_render* r) {
+    LOCK_RENDER(r);
+    HIP_TRY(hipMemsetAsync(r->fb, 0, (size_t)r->width * r->height * 3 * sizeof(float), r->ctx->stream));
+    return CHUNKY_OK;
+}
+
+static hipError_t get_event(chunky_render* r, hipEvent_t* e) {
+    if (!r->free_events.empty()) {
+        *e = r->free_events.back();
+        r->free_events.pop_back();
+        return hipSuccess;
+    }
+    return hipEventCreate(e);
+}
+
+static int collect_timing(chunky_render* r) {
+    for (auto& p : r->pending) {
+        float ms = 0;
+        HIP_TRY(hipEventSynchronize(p.second));
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        r->timed_ms += ms;
+        r->timed_launches += 1;
+        r->free_events.push_back(p.first);
+        r->free_events.push_back(p.second);
+    }
+    r->pending.clear();
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int n, int first_buffer_spp) {
+    LOCK_RENDER(r);
+    if (n < 0 || (n > 0 && !seeds) || first_buffer_spp < 0) return fail(CHUNKY_E_INVALID, "render_passes: bad arguments");
+    if (!r->have_camera) return fail(CHUNKY_E_STATE, "render_passes before set_camera");
+    SceneView S;
+    if (int rc = scene_view(r->scene, &S)) return rc;
+    if (r->pending.size() > 4096)
+        if (int rc = collect_timing(r)) return rc;
+    for (int done = 0; done < n;) {
+        PassSeeds ps;
+        ps.n = (n - done) < kMaxPassesPerLaunch ? (n - done) : kMaxPassesPerLaunch;
+        ps.first_spp = first_buffer_spp + done;
+        memcpy(ps.seed, seeds + done, (size_t)ps.n * 4);
+        hipEvent_t e0, e1;
+        HIP_TRY(get_event(r, &e0));
+        HIP_TRY(get_event(r, &e1));
+        HIP_TRY(hipEventRecord(e0, r->ctx->stream));
+        HIP_TRY(launch_render(r->kernel_variant, S, r->cam, r->opts, r->shard, ps, r->fb, r->ctx->stream));
+        HIP_TRY(hipEventRecord(e1, r->ctx->stream));
+        r->pending.emplace_back(e0, e1);
+        done += ps.n;
+    }
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_sync(chunky_render* r) {
+    LOCK_RENDER(r);
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_read(chunky_render* r, float* out, int64_t n) {
+    LOCK_RENDER(r);
+    int64_t need = (int64_t)r->width * r->height * 3;
+    if (!out || n != need) return fail(CHUNKY_E_INVALID, "render_read: need %lld floats, got %lld", (long long)need, (long long)n);
+    HIP_TRY(hipMemcpyAsync(out, r->fb, (size_t)n * 4, hipMemcpyDeviceToHost, r->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches) {
+    LOCK_RENDER(r);
+    if (int rc = collect_timing(r)) return rc;
+    if (total_ms) *total_ms = r->timed_ms;
+    if (launches) *launches = r->timed_launches;
+    r->timed_ms = 0;
+    r->timed_launches = 0;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_preview(chunky_render* r, int32_t* argb_out) {
+    LOCK_RENDER(r);
+    if (!argb_out) return fail(CHUNKY_E_INVALID, "preview: NULL output");
+    if (!r->have_camera) return fail(CHUNKY_E_STATE, "preview before set_camera");
+    SceneView S;
+    if (int rc = scene_view(r->scene, &S)) return rc;
+    DevBuf out;
+    size_t bytes = (size_t)r->width * r->height * 4;
+    HIP_TRY(hipMalloc(&out.p, bytes));
+    out.bytes = bytes;
+    HIP_TRY(launch_preview(S, r->cam, r->opts, (int*)out.p, r->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(argb_out, out.p, bytes, hipMemcpyDeviceToHost, r->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_trace_records(chunky_render* r, int32_t seed, const int32_t* gids, int n,
+                                           chunky_hit_record* records, int32_t* counts, float* radiance) {
+    LOCK_RENDER(r);
+    if (n < 0 || (n > 0 && (!gids || !records || !counts || !radiance))) return fail(CHUNKY_E_INVALID, "trace_records: bad arguments");
+    if (!r->have_camera) return fail(CHUNKY_E_STATE, "trace_records before set_camera");
+    if (n == 0) return CHUNKY_OK;
+    for (int i = 0; i < n; i++)
+        if (gids[i] < 0 || gids[i] >= r->width * r->height) return fail(CHUNKY_E_INVALID, "trace_records: gid %d outside the image", gids[i]);
+    SceneView S;
+    if (int rc = scene_view(r->scene, &S)) return rc;
+    DevBuf dg, dr, dc, dq;
+    hipStream_t st = r->ctx->stream;
+    HIP_TRY(dg.upload(gids, (size_t)n * 4, st));
+    HIP_TRY(hipMalloc(&dr.p, (size_t)n * kMaxTraces * sizeof(HitRecord)));
+    HIP_TRY(hipMalloc(&dc.p, (size_t)n * 4));
+    HIP_TRY(hipMalloc(&dq.p, (size_t)n * 12));
+    HIP_TRY(hipMemsetAsync(dr.p, 0, (size_t)n * kMaxTraces * sizeof(HitRecord), st));
+    HIP_TRY(launch_trace_records(S, r->cam, r->opts, seed, (const int*)dg.p, n, (HitRecord*)dr.p, (int*)dc.p, (float*)dq.p, st));
+    HIP_TRY(hipMemcpyAsync(records, dr.p, (size_t)n * kMaxTraces * sizeof(HitRecord), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(counts, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(radiance, dq.p, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CHUNKY_OK;
+}
+
+// ------------------------------------------------------------------------------------ host loop
+namespace {
+struct JavaRandom {  // java.util.Random: 48-bit LCG, nextInt() = top 32 bits
+    uint64_t s;
+    explicit JavaRandom(int64_t seed) : s(((uint64_t)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1)) {}
+    int32_t next_int() {
+        s = (s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+        return (int32_t)(int64_t)(s >> 16);
+    }
+};
+}  // namespace
+
+extern "C" int chunky_java_random_ints(int64_t seed, int32_t* out, int n) {
+    if (n < 0 || (n > 0 && !out)) return fail(CHUNKY_E_INVALID, "java_random_ints: bad arguments");
+    JavaRandom rnd(seed);
+    for (int i = 0; i < n; i++) out[i] = rnd.next_int();
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
+                                 int32_t merge_interval, chunky_post_render_fn post_render, void* user) {
+    if (!r || !r->ctx) return fail(CHUNKY_E_INVALID, "NULL render");
+    if (!sample_buffer || !scene_spp) return fail(CHUNKY_E_INVALID, "render_run: NULL buffer");
+    if (merge_interval < 1) merge_interval = 1024;  // OpenClPathTracingRenderer.java:158
+    const int64_t n = (int64_t)r->width * r->height * 3;
+    std::vector<float> pass_buffer((size_t)n);
+    JavaRandom rnd(0);                 // :95
+    int logical_spp = *scene_spp;      // :91
+    int samp_spp = *scene_spp;         // sceneSpp[0], :92
+    auto last_callback = std::chrono::steady_clock::now();
+    if (int rc = chunky_render_reset(r)) return rc;  // new float[] passBuffer uploaded with the buffer, :61,71
+    int launch_passes = 1;             // grows until a launch takes ~50 ms, so postRender is polled often enough
+    while (logical_spp < target_spp) { // :102
+        int buffer_spp = 0;            // bufferSppReal
+        int until_merge = target_spp - logical_spp < merge_interval ? target_spp - logical_spp : merge_interval;
+        bool stop = false;
+        while (buffer_spp < until_merge) {
+            int m = until_merge - buffer_spp < launch_passes ? until_merge - buffer_spp : launch_passes;
+            std::vector<int32_t> seeds((size_t)m);
+            for (int k = 0; k < m; k++) seeds[(size_t)k] = rnd.next_int();  // :107
+            auto t0 = std::chrono::steady_clock::now();
+            if (int rc = chunky_render_passes(r, seeds.data(), m, buffer_spp)) return rc;
+            if (int rc = chunky_render_sync(r)) return rc;                  // clWaitForEvents, :141
+            auto t1 = std::chrono::steady_clock::now();
+            buffer_spp += m;
+            *scene_spp += m;                                                 // :144
+            double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            if (ms < 25.0 && launch_passes < kMaxPassesPerLaunch) launch_passes *= 2;
+            if (ms > 90.0 && launch_passes > 1) launch_passes /= 2;
+            if (post_render && std::chrono::duration<double, std::milli>(t1 - last_callback).count() > 100.0) {  // :153-157
+                last_callback = t1;
+                if (post_render(user)) {
+                    stop = true;
+                    break;
+                }
+            }
+        }
+        if (post_render && post_render(user)) stop = true;                   // :163
+        if (stop && buffer_spp == 0) return fail(CHUNKY_E_ABORTED, "stopped by postRender");
+        if (int rc = chunky_render_read(r, pass_buffer.data(), n)) return rc;  // :164-166
+        const double sinv = 1.0 / (samp_spp + buffer_spp);                   // :169
+        const double a = samp_spp, b = buffer_spp;
+        for (int64_t i = 0; i < n; i++)                                       // :173
+            sample_buffer[i] = (sample_buffer[i] * a + (double)pass_buffer[(size_t)i] * b) * sinv;
+        samp_spp += buffer_spp;
+        logical_spp += buffer_spp;                                            // :178
+        if (stop) return fail(CHUNKY_E_ABORTED, "stopped by postRender");
+        // bufferSppReal = 0 (:170): the next pass runs with spp = 0, i.e. (mean*0 + c)/1 — no reset needed
+    }
+    return CHUNKY_OK;
+}
+
+// ------------------------------------------------------------------------------------ self test
+extern "C" int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const float* a, const float* b, float* out) {
+    if (!ctx) return fail(CHUNKY_E_INVALID, "NULL context");
+    if (n < 0 || (n > 0 && (!a || !b || !out))) return fail(CHUNKY_E_INVALID, "selftest_math: bad arguments");
+    if (n == 0) return CHUNKY_OK;
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf da, db, dout;
+    HIP_TRY(da.upload(a, (size_t)n * 4, ctx->stream));
+    HIP_TRY(db.upload(b, (size_t)n * 4, ctx->stream));
+    HIP_TRY(hipMalloc(&dout.p, (size_t)n * 4));
+    HIP_TRY(launch_math_selftest(which, n, (const float*)da.p, (const float*)db.p, (float*)dout.p, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CHUNKY_OK;
+}

@@ -1,0 +1,49 @@
+// kernels.hpp — host-visible launch interface of kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chunky {
+
+struct SceneView;
+struct CameraView;
+struct RenderOpts;
+
+constexpr int kMaxTraces = 10;        // 5 path segments x (main + shadow trace)
+constexpr int kBvhStackEntries = 64;  // K/bvh.h:38
+
+// Image-tile ownership of this process: tiles of `tile` consecutive pixel
+// indices dealt round-robin over `world` ranks; n_local = pixel slots owned by `rank`.
+struct ShardView {
+    int rank, world, tile, n_local;
+};
+
+// Layout shared with include/chunky_hip.h (chunky_hit_record) and oracle/oracle_scene.h.
+struct HitRecord {
+    int32_t hit;
+    int32_t material;
+    float distance;
+    float normal[3];
+    float color[4];
+    float emittance;
+    float point[3];
+};
+
+// Seeds of the passes one launch runs, passed by value in the kernel-argument segment (wave-uniform
+// scalar loads, no per-launch host->device copy): pass k uses seed[k] and bufferSpp first_spp + k
+// (OpenClPathTracingRenderer.java:106-109).
+constexpr int kMaxPassesPerLaunch = 64;
+struct PassSeeds {
+    int n, first_spp;
+    int seed[kMaxPassesPerLaunch];
+};
+
+hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
+                         const PassSeeds& P, float* res, hipStream_t stream);
+hipError_t launch_trace_records(const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
+                                const int* gids_dev, int n, HitRecord* out, int* counts, float* radiance,
+                                hipStream_t stream);
+hipError_t launch_preview(const SceneView& S, const CameraView& C, const RenderOpts& O, int* argb, hipStream_t stream);
+hipError_t launch_math_selftest(int which, int n, const float* a, const float* b, float* out, hipStream_t stream);
+
+}  // namespace chunky

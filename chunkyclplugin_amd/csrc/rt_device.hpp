@@ -1,0 +1,500 @@
+// rt_device.hpp — gfx950 device building blocks of the Chunky path tracer.
+//
+// Each helper states which lines of the reference kernel
+// (/root/reference/src/main/opencl/kernel/include/, "K/") define the arithmetic it must reproduce
+// bit for bit.  The arithmetic contract (IEEE binary32, binary64 at the reference's double-literal
+// sites, no contraction, OpenCL builtins as defined in rt_math.h) is SURVEY.md Appendix E; this
+// translation unit is compiled with -ffp-contract=off.
+//
+// Nothing here mirrors the reference's control flow: the helpers are leaf computations that the
+// kernels in kernels.hip schedule per wavefront.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_math.h"
+
+namespace chunky {
+
+constexpr float kEps = 0.000005f;    // K/constants.h:4
+constexpr float kOffset = 0.0001f;   // K/constants.h:5
+constexpr int kAnyType = 0x7FFFFFFE; // K/block.h:32
+
+struct f3 {
+    float x, y, z;
+};
+struct f4 {
+    float x, y, z, w;
+};
+#define DEV __device__ __forceinline__
+
+DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+DEV f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+DEV f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+DEV float dot(f3 a, f3 b) { return rt_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
+DEV f3 cross(f3 a, f3 b) {
+    return f3{rt_cross_c(a.y, b.z, a.z, b.y), rt_cross_c(a.z, b.x, a.x, b.z), rt_cross_c(a.x, b.y, a.y, b.x)};
+}
+DEV f3 normalize(f3 a) { return a * rt_rlen3(a.x, a.y, a.z); }
+DEV f3 rcp3(f3 a) { return f3{1.0f / a.x, 1.0f / a.y, 1.0f / a.z}; }
+DEV float as_float(int i) { return __int_as_float(i); }
+
+// ---------------------------------------------------------------------------------------------
+// Device view of one packed scene (wire formats: SURVEY.md Appendix A).  Passed by value as a
+// kernel argument so every field is wave-uniform (SGPR-resident).
+struct SceneView {
+    const int* __restrict__ octree;   // K/rayTracer.cl:16
+    const int* __restrict__ blocks;   // :18
+    const int* __restrict__ quads;    // :19
+    const int* __restrict__ aabbs;    // :20
+    const int* __restrict__ world_bvh;  // :22
+    const int* __restrict__ actor_bvh;  // :23
+    const int* __restrict__ trigs;    // :24
+    const uint32_t* __restrict__ atlas;  // :26  RGBA8 texels as little-endian uint32, [layer][y][x]
+    const int* __restrict__ materials;   // :27
+    const uint32_t* __restrict__ sky;    // :29  RGBA8 [y][x]
+    int octree_depth;
+    int atlas_w, atlas_h, atlas_layers;
+    int sky_w, sky_h;
+    float sky_intensity;              // :30
+    // Sun_new (K/sky.h:19-40) evaluated once on the host with the same rt_math.h
+    int sun_flags, sun_tex_size, sun_tex;
+    float sun_intensity;
+    f3 su, sv, sw;
+    float sun_radius_cos;             // cos(0.03f), K/sky.h:73
+    int world_bvh_empty, actor_bvh_empty;  // K/bvh.h:23-32 sentinel, tested at upload
+};
+
+struct CameraView {
+    const float* __restrict__ rays;  // projector -1: W*H*6 floats (K/camera.h:8-11)
+    int projector_type;
+    float pos[3], m[9];              // ClCamera.java:42-52
+    float aperture, subject_distance, fov_tan;
+    int width, height;
+    float half_width, inv_height;    // K/rayTracer.cl:66-67 (double sites, rounded once on the host)
+};
+
+struct RenderOpts {
+    int draw_depth;       // 256, K/rayTracer.cl:94
+    int max_depth;        // 5,   K/rayTracer.cl:107
+    float emitter_scale;  // 13,  K/rayTracer.cl:99
+};
+
+// Per-path state: Pixel + Ray + IntersectionRecord of K/wavefront.h:6-51, flattened.
+struct Hit {
+    float distance;
+    int material;
+    f3 normal;
+    f4 color;
+    float emittance;
+};
+
+// ---------------------------------------------------------------------------------------------
+// slab tests — K/primitives.h:30-61
+struct Slabs {
+    float t1x, t1y, t1z, t2x, t2y, t2z;
+};
+DEV Slabs slabs(float x0, float x1, float y0, float y1, float z0, float z1, f3 o, f3 inv) {
+    return Slabs{(x0 - o.x) * inv.x, (y0 - o.y) * inv.y, (z0 - o.z) * inv.z,
+                 (x1 - o.x) * inv.x, (y1 - o.y) * inv.y, (z1 - o.z) * inv.z};
+}
+DEV float slab_near(const Slabs& s) {
+    return rt_fmax(rt_fmin(s.t1x, s.t2x), rt_fmax(rt_fmin(s.t1y, s.t2y), rt_fmin(s.t1z, s.t2z)));
+}
+DEV float slab_far(const Slabs& s) {
+    return rt_fmin(rt_fmax(s.t1x, s.t2x), rt_fmin(rt_fmax(s.t1y, s.t2y), rt_fmax(s.t1z, s.t2z)));
+}
+// AABB_quick_intersect: NaN = miss
+DEV float box_quick(float x0, float x1, float y0, float y1, float z0, float z1, f3 o, f3 inv) {
+    Slabs s = slabs(x0, x1, y0, y1, z0, z1, o, inv);
+    float tn = slab_near(s), tf = slab_far(s);
+    return (tf < tn) ? rt_nan() : tn;
+}
+// AABB_exit
+DEV float box_exit(float x0, float x1, float y0, float y1, float z0, float z1, f3 o, f3 inv) {
+    return slab_far(slabs(x0, x1, y0, y1, z0, z1, o, inv));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K/utils.h:6-14 (divide by 256, exact)
+DEV f4 color_from_argb(unsigned argb) {
+    const float k = 1.0f / 256.0f;
+    return f4{(float)((argb >> 16) & 0xFF) * k, (float)((argb >> 8) & 0xFF) * k, (float)(argb & 0xFF) * k,
+              (float)((argb >> 24) & 0xFF) * k};
+}
+DEV f4 unpack_unorm8(uint32_t t) {
+    return f4{rt_unorm8(t & 0xFF), rt_unorm8((t >> 8) & 0xFF), rt_unorm8((t >> 16) & 0xFF), rt_unorm8(t >> 24)};
+}
+
+// K/textureAtlas.h:10-28: nearest, unnormalised, clamp-to-edge, layer clamped
+DEV uint32_t atlas_texel(const SceneView& S, float u, float v, int location, int size) {
+    int width = (size >> 16) & 0xFFFF, height = size & 0xFFFF;
+    v = 1 - v;
+    int x = rt_clampi((int)((u - kEps) * (float)width), 0, width - 1);
+    int y = rt_clampi((int)((v - kEps) * (float)height), 0, height - 1);
+    x += ((location >> 22) & 0x1FF) * 16;
+    y += ((location >> 13) & 0x1FF) * 16;
+    int d = location & 0x7FFFF;
+    x = rt_clampi(x, 0, S.atlas_w - 1);
+    y = rt_clampi(y, 0, S.atlas_h - 1);
+    d = rt_clampi(d, 0, S.atlas_layers - 1);
+    return S.atlas[((size_t)d * S.atlas_h + y) * S.atlas_w + x];
+}
+
+// K/material.h:31-82.  `shade` = false skips the writes that only matter to the main record
+// (shadow rays need the accept/reject decision only).
+DEV bool material_sample(const SceneView& S, int material, float u, float v, Hit& h) {
+    const int* m = S.materials + material;
+    unsigned flags = m[0], tint = m[1], tex_size = m[2], color_w = m[3], ne = m[4];
+    f4 c = (flags & 4) ? unpack_unorm8(atlas_texel(S, u, v, (int)color_w, (int)tex_size)) : color_from_argb(color_w);
+    if (!(c.w > kEps)) return false;
+    unsigned tt = tint >> 24;
+    if (tt == 0xFF || tt == 1 || tt == 2 || tt == 3) {
+        unsigned tc = tt == 0xFF ? tint : (tt == 1 ? 0xFF71A74Du : (tt == 2 ? 0xFF8EB971u : 0xFF3F76E4u));
+        f4 t = color_from_argb(tc);
+        c = f4{c.x * t.x, c.y * t.y, c.z * t.z, c.w * t.w};
+    }
+    h.color = c;
+    if (flags & 2)
+        h.emittance = unpack_unorm8(atlas_texel(S, u, v, (int)ne, (int)tex_size)).w;
+    else
+        h.emittance = (float)((double)(ne & 0xFF) / 255.0);  // double site, K/material.h:79
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Entry face + UV of a slab hit: the equality chain of K/primitives.h:86-109 / :136-159, last
+// match wins.  p = origin + tmin * dir as the caller defines dir.
+struct Face {
+    f3 n;
+    float u, v;
+};
+DEV Face face_unit(const Slabs& s, float tmin, f3 p) {  // AABB_full_intersect on the unit cube
+    // d = 1/(max-min) = 1 exactly for the unit cube, (p - 0) * 1 = p exactly
+    Face f{mk3(0, 0, 0), 0, 0};
+    if (s.t1x == tmin) f = Face{mk3(-1, 0, 0), 1 - p.z, p.y};
+    if (s.t2x == tmin) f = Face{mk3(1, 0, 0), p.z, p.y};
+    if (s.t1y == tmin) f = Face{mk3(0, -1, 0), p.x, 1 - p.z};
+    if (s.t2y == tmin) f = Face{mk3(0, 1, 0), p.x, p.z};
+    if (s.t1z == tmin) f = Face{mk3(0, 0, -1), p.x, p.y};
+    if (s.t2z == tmin) f = Face{mk3(0, 0, 1), 1 - p.x, p.y};
+    return f;
+}
+DEV Face face_map2(const Slabs& s, float tmin, f3 p) {  // AABB_full_intersect_map_2
+    Face f{mk3(0, 0, 0), 0, 0};
+    if (s.t1x == tmin) f = Face{mk3(-1, 0, 0), p.z, p.y};
+    if (s.t2x == tmin) f = Face{mk3(1, 0, 0), 1 - p.z, p.y};
+    if (s.t1y == tmin) f = Face{mk3(0, -1, 0), p.x, p.z};
+    if (s.t2y == tmin) f = Face{mk3(0, 1, 0), p.x, 1 - p.z};
+    if (s.t1z == tmin) f = Face{mk3(0, 0, -1), 1 - p.x, p.y};
+    if (s.t2z == tmin) f = Face{mk3(0, 0, 1), p.x, p.y};
+    return f;
+}
+
+// Full cube (block model type 1) — K/block.h:48-65 with K/primitives.h:66-112.
+// `no` = march position minus d*OFFSET minus the block corner; the reference passes the march
+// position `pos` where a direction is expected (K/block.h:52), so the UV point is no + tmin*pos.
+DEV float cube_hit(const SceneView& S, int material, f3 no, f3 pos, f3 inv, Hit& h) {
+    Slabs s = slabs(0, 1, 0, 1, 0, 1, no, inv);
+    float tn = slab_near(s), tf = slab_far(s);
+    if (tf < tn) return rt_nan();
+    Face f = face_unit(s, tn, no + pos * tn);
+    h.normal = f.n;  // written before the material test (K/block.h:59-60)
+    return material_sample(S, material, f.u, f.v, h) ? tn - kOffset : rt_nan();
+}
+
+// AABB model (type 2) — K/block.h:66-91, K/primitives.h:165-260
+DEV float aabb_model_hit(const SceneView& S, int ptr, f3 no, f3 dir, f3 inv, Hit& h) {
+    const int* __restrict__ model = S.aabbs + ptr;
+    int boxes = model[0];
+    float best = rt_inf();
+    bool hit = false;
+    for (int i = 0; i < boxes; i++) {
+        const int* b = model + 1 + i * 13;
+        Slabs s = slabs(as_float(b[0]), as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]),
+                        as_float(b[5]), no, inv);
+        float tn = slab_near(s), tf = slab_far(s);
+        if (tf < tn) continue;
+        if (tn != tn || tn >= best || tn < -kEps) continue;
+        Face f = face_map2(s, tn, no + dir * tn);
+        int fl_all = b[6];
+        // face -> material / flags: K/primitives.h:209-234 (both z tests are "== -1"; +z keeps the
+        // east material with flags 0, see oracle/port.c textured_box)
+        int mat = b[8], fl = 0;
+        if (f.n.x == 1) { mat = b[8]; fl = fl_all >> 4; }
+        if (f.n.z == -1) { mat = b[9]; fl = fl_all >> 8; }
+        if (f.n.x == -1) { mat = b[10]; fl = fl_all >> 12; }
+        if (f.n.y == 1) { mat = b[11]; fl = fl_all >> 16; }
+        if (f.n.y == -1) { mat = b[12]; fl = fl_all >> 20; }
+        if (fl & 8) continue;
+        float u = f.u, v = f.v;
+        if (fl & 4) u = 1 - u;
+        if (fl & 2) v = 1 - v;
+        if (fl & 1) { float t = u; u = v; v = t; }
+        if (material_sample(S, mat, u, v, h)) {
+            h.normal = f.n;
+            best = tn;
+            hit = true;
+        }
+    }
+    return hit ? best : rt_nan();
+}
+
+// Quad model (type 3) — K/block.h:92-116, K/primitives.h:263-319
+DEV float quad_model_hit(const SceneView& S, int ptr, f3 no, f3 dir, Hit& h) {
+    const int* __restrict__ model = S.quads + ptr;
+    int quads = model[0];
+    float best = rt_inf();
+    bool hit = false;
+    for (int i = 0; i < quads; i++) {
+        const int* q = model + 1 + i * 15;
+        f3 qo = mk3(as_float(q[0]), as_float(q[1]), as_float(q[2]));
+        f3 xv = mk3(as_float(q[3]), as_float(q[4]), as_float(q[5]));
+        f3 yv = mk3(as_float(q[6]), as_float(q[7]), as_float(q[8]));
+        f3 n = normalize(cross(xv, yv));
+        float denom = dot(dir, n);
+        if (!(denom < -kEps)) continue;
+        float t = -(dot(no, n) - dot(n, qo)) / denom;
+        if (!(t > -kEps && t < best)) continue;
+        f3 pt = (no + dir * t) - qo;
+        float u = dot(pt, xv) / dot(xv, xv);
+        float v = dot(pt, yv) / dot(yv, yv);
+        if (!(u >= 0 && u <= 1 && v >= 0 && v <= 1)) continue;
+        float tu = as_float(q[9]) + (u * as_float(q[10]));
+        float tv = as_float(q[11]) + (v * as_float(q[12]));
+        if (material_sample(S, q[13], tu, tv, h)) {
+            h.normal = n;
+            best = t;
+            hit = true;
+        }
+    }
+    return hit ? best : rt_nan();
+}
+
+// BlockPalette_intersectBlock — K/block.h:30-118.  bx/by/bz = integer cell of the march point.
+DEV float block_hit(const SceneView& S, int block, int bx, int by, int bz, f3 pos, f3 dir, f3 inv, Hit& h) {
+    if (block == kAnyType) return rt_nan();
+    int type = S.blocks[block], ptr = S.blocks[block + 1];
+    f3 no = (pos - dir * kOffset) - mk3((float)bx, (float)by, (float)bz);
+    switch (type) {
+        case 1: return cube_hit(S, ptr, no, pos, inv, h);
+        case 2: return aabb_model_hit(S, ptr, no, dir, inv, h);
+        case 3: return quad_model_hit(S, ptr, no, dir, h);
+        default: return rt_nan();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangle — K/primitives.h:321-409 (Moller-Trumbore, single-sided = det < -EPS)
+DEV float triangle_hit(const int* __restrict__ t, float best, f3 o, f3 dir, f3& n, float& u, float& v, int& mat) {
+    int flags = t[0];
+    f3 e1 = mk3(as_float(t[1]), as_float(t[2]), as_float(t[3]));
+    f3 e2 = mk3(as_float(t[4]), as_float(t[5]), as_float(t[6]));
+    f3 to = mk3(as_float(t[7]), as_float(t[8]), as_float(t[9]));
+    f3 pvec = cross(dir, e2);
+    float det = dot(e1, pvec);
+    if ((flags >> 8) & 1) {
+        if (det > -kEps && det < kEps) return rt_nan();
+    } else if (det > -kEps) {
+        return rt_nan();
+    }
+    float recip = 1 / det;
+    f3 tvec = o - to;
+    float uu = dot(tvec, pvec) * recip;
+    if (uu < 0 || uu > 1) return rt_nan();
+    f3 qvec = cross(tvec, e1);
+    float vv = dot(dir, qvec) * recip;
+    if (vv < 0 || (uu + vv) > 1) return rt_nan();
+    float tt = dot(e2, qvec) * recip;
+    if (tt > kEps && tt < best) {
+        float w = 1 - uu - vv;
+        u = as_float(t[13]) * uu + as_float(t[15]) * vv + as_float(t[17]) * w;
+        v = as_float(t[14]) * uu + as_float(t[16]) * vv + as_float(t[18]) * w;
+        n = mk3(as_float(t[10]), as_float(t[11]), as_float(t[12]));
+        mat = t[19];
+        return tt;
+    }
+    return rt_nan();
+}
+
+// Bvh_intersect — K/bvh.h:22-113.  `stack` is this lane's 64-entry to-visit stack; the caller
+// chooses where it lives (LDS column or scratch).
+template <typename Stack>
+DEV bool bvh_hit(const SceneView& S, const int* __restrict__ bvh, f3 o, f3 d, Hit& h, Stack& stack) {
+    const int* __restrict__ trigs = S.trigs;
+    bool hit = false;
+    int to_visit = 0, cur = 0;
+    f3 inv = rcp3(d);
+    for (;;) {
+        int head = bvh[cur];
+        if (head <= 0) {
+            int prim = -head;
+            int n = trigs[prim];
+            for (int i = 0; i < n; i++) {
+                f3 nn;
+                float u, v;
+                int mat;
+                float dist = triangle_hit(trigs + prim + 1 + 20 * i, h.distance, o, d, nn, u, v, mat);
+                if (dist == dist && material_sample(S, mat, u, v, h)) {
+                    h.normal = nn;
+                    h.distance = dist;
+                    hit = true;
+                }
+            }
+            if (to_visit == 0) break;
+            cur = stack.pop(--to_visit);
+        } else {
+            int second = head;
+            const int* a = bvh + cur + 7;
+            const int* b = bvh + second;
+            float t1 = box_quick(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
+                                 as_float(a[6]), o, inv);
+            float t2 = box_quick(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
+                                 as_float(b[6]), o, inv);
+            bool miss1 = (t1 != t1) || t1 > h.distance;
+            bool miss2 = (t2 != t2) || t2 > h.distance;
+            if (miss1) {
+                if (miss2) {
+                    if (to_visit == 0) break;
+                    cur = stack.pop(--to_visit);
+                } else {
+                    cur = second;
+                }
+            } else if (miss2) {
+                cur += 7;
+            } else if (t1 < t2) {
+                stack.push(to_visit++, second);
+                cur += 7;
+            } else {
+                stack.push(to_visit++, cur + 7);
+                cur = second;
+            }
+        }
+    }
+    return hit;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sky_intersect — K/sky.h:95-106 with the linear / mirrored-repeat sampler contract of rt_math.h
+DEV f4 sky_color(const SceneView& S, f3 d) {
+    float theta = rt_atan2(d.z, d.x);
+    theta = theta / (RT_PI_F * 2);
+    theta = rt_fmod1(rt_fmod1(theta) + 1);
+    float phi = (rt_asin(rt_clamp(d.y, -1.0f, 1.0f)) + RT_PI_2_F) * RT_1_PI_F;
+    int i0, i1, j0, j1;
+    float a, b;
+    rt_mirror_linear(theta, S.sky_w, &i0, &i1, &a);
+    rt_mirror_linear(phi, S.sky_h, &j0, &j1, &b);
+    f4 t00 = unpack_unorm8(S.sky[j0 * S.sky_w + i0]);
+    f4 t10 = unpack_unorm8(S.sky[j0 * S.sky_w + i1]);
+    f4 t01 = unpack_unorm8(S.sky[j1 * S.sky_w + i0]);
+    f4 t11 = unpack_unorm8(S.sky[j1 * S.sky_w + i1]);
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float k = S.sky_intensity;
+    return f4{(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x) * k,
+              (w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y) * k,
+              (w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z) * k,
+              (w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w) * k};
+}
+
+// Sun_intersect — K/sky.h:42-66: adds the sun-disc texel (x intensity) to c
+DEV void sun_disc(const SceneView& S, f3 d, f4& c) {
+    if (!(S.sun_flags & 1) || dot(d, S.sw) < 0.5f) return;
+    const float radius = 0.03f;
+    const float width = radius * 4;
+    const float width2 = width * 2;
+    float a = RT_PI_2_F - rt_acos(dot(d, S.su)) + width;
+    if (a >= 0 && a < width2) {
+        float b = RT_PI_2_F - rt_acos(dot(d, S.sv)) + width;
+        if (b >= 0 && b < width2) {
+            f4 t = unpack_unorm8(atlas_texel(S, a / width2, b / width2, S.sun_tex, S.sun_tex_size));
+            c.x += t.x * S.sun_intensity;
+            c.y += t.y * S.sun_intensity;
+            c.z += t.z * S.sun_intensity;
+            c.w += t.w * S.sun_intensity;
+        }
+    }
+}
+
+// intersectSky — K/kernel.h:26-31: returns color.xyz * throughput * emittance
+DEV f3 sky_radiance(const SceneView& S, f3 d, f3 throughput, float emittance) {
+    f4 c = sky_color(S, d);
+    sun_disc(S, d, c);
+    return (mk3(c.x, c.y, c.z) * throughput) * emittance;
+}
+
+// Sun_sampleDirection — K/sky.h:68-93 (direction = u * v component-wise, then += w)
+DEV f3 sun_sample(const SceneView& S, unsigned& rng) {
+    float x1 = rt_pcg_float(&rng), x2 = rt_pcg_float(&rng);
+    float cos_a = 1 - x1 + x1 * S.sun_radius_cos;
+    float sin_a = rt_sqrt(1 - cos_a * cos_a);
+    float phi = 2 * RT_PI_F * x2;
+    float sp, cp;
+    rt_sincos(phi, &sp, &cp);
+    f3 u = S.su * (cp * sin_a);
+    f3 v = S.sv * (sp * sin_a);
+    f3 w = S.sw * cos_a;
+    return normalize((u * v) + w);
+}
+
+// nextPath — K/kernel.h:46-98: cosine-weighted bounce about n (double compare at :66)
+DEV f3 diffuse_bounce(f3 n, unsigned& rng) {
+    float x1 = rt_pcg_float(&rng), x2 = rt_pcg_float(&rng);
+    float r = rt_sqrt(x1);
+    float theta = 2 * RT_PI_F * x2;
+    float st, ct;
+    rt_sincos(theta, &st, &ct);
+    float tx = r * ct, ty = r * st, tz = rt_sqrt(1 - x1);
+    float xx, xy, xz = 0;
+    if ((double)rt_fabs(n.x) > 0.1) {
+        xx = 0;
+        xy = 1;
+    } else {
+        xx = 1;
+        xy = 0;
+    }
+    float ux = xy * n.z - xz * n.y;
+    float uy = xz * n.x - xx * n.z;
+    float uz = xx * n.y - xy * n.x;
+    r = 1 / rt_sqrt(ux * ux + uy * uy + uz * uz);
+    ux *= r;
+    uy *= r;
+    uz *= r;
+    float vx = uy * n.z - uz * n.y;
+    float vy = uz * n.x - ux * n.z;
+    float vz = ux * n.y - uy * n.x;
+    return f3{ux * tx + vx * ty + n.x * tz, uy * tx + vy * ty + n.y * tz, uz * tx + vz * ty + n.z * tz};
+}
+
+// Primary ray — K/rayTracer.cl:55-91, K/camera.h:8-32.  `unit_dir` = the preview kernel's extra
+// normalize (K/rayTracer.cl:186).
+DEV void primary_ray(const CameraView& C, int gid, unsigned& rng, bool unit_dir, f3& o, f3& d) {
+    if (C.projector_type != -1) {
+        float x = -C.half_width + ((float)(gid % C.width) + rt_pcg_float(&rng)) * C.inv_height;
+        float y = (float)(-0.5 + (double)(((float)(gid / C.width) + rt_pcg_float(&rng)) * C.inv_height));
+        f3 lo = mk3(0, 0, 0);
+        f3 ld = mk3(C.fov_tan * x, C.fov_tan * y, 1.0f);
+        if (C.aperture > 0) {
+            ld = ld * (C.subject_distance / ld.z);
+            float r = rt_sqrt(rt_pcg_float(&rng)) * C.aperture;
+            float theta = (float)((double)(rt_pcg_float(&rng) * RT_PI_F) * 2.0);
+            float st, ct;
+            rt_sincos(theta, &st, &ct);
+            float rx = ct * r, ry = st * r;
+            ld = ld - mk3(rx, ry, 0);
+            lo = lo + mk3(rx, ry, 0);
+        }
+        if (unit_dir) ld = normalize(ld);
+        f3 m1 = mk3(C.m[0], C.m[1], C.m[2]), m2 = mk3(C.m[3], C.m[4], C.m[5]), m3 = mk3(C.m[6], C.m[7], C.m[8]);
+        d = mk3(dot(m1, ld), dot(m2, ld), dot(m3, ld));
+        o = mk3(dot(m1, lo), dot(m2, lo), dot(m3, lo)) + mk3(C.pos[0], C.pos[1], C.pos[2]);
+    } else {
+        const float* r = C.rays + (size_t)gid * 6;
+        o = mk3(r[0], r[1], r[2]);
+        d = mk3(r[3], r[4], r[5]);
+    }
+}
+
+}  // namespace chunky

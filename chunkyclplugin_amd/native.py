@@ -1,0 +1,134 @@
+"""ctypes binding of the C ABI declared in include/chunky_hip.h (libchunky_hip.so).
+
+This is the only way Python reaches the device path; there is no fallback.  If the shared library
+is missing it is built with hipcc (`build()`); if that is impossible, or no HIP device is present
+when a context is created, the error propagates — nothing here routes to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+from typing import List, Optional
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libchunky_hip.so")
+HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "chunky_hip.h")
+SOURCES = ["kernels.hip", "capi.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+MAX_TRACES = 10
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("material", "<i4"), ("distance", "<f4"), ("normal", "<f4", 3),
+                      ("color", "<f4", 4), ("emittance", "<f4"), ("point", "<f4", 3)])
+
+PALETTE_BLOCK, PALETTE_MATERIAL, PALETTE_AABB, PALETTE_QUAD, PALETTE_TRIG = range(5)
+BVH_WORLD, BVH_ACTOR = 0, 1
+OPT_DRAW_DEPTH, OPT_MAX_DEPTH, OPT_EMITTER_SCALE, OPT_KERNEL = range(4)
+E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_ABORTED = -1, -2, -3, -4, -5
+
+
+class ChunkyHipError(RuntimeError):
+    """Raised for any non-zero status (the JNI layer would throw RuntimeException the same way;
+    the reference gets CLException from JOCL, RendererInstance.java:36)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"chunky-hip error {code}: {message}")
+        self.code = code
+
+
+def _needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force or _needs_build():
+        cmd = ["hipcc", *HIPCC_FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + proc.stderr[-4000:])
+    return LIB_PATH
+
+
+def declared_symbols() -> List[str]:
+    """Every function include/chunky_hip.h declares."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(chunky_[a-z_0-9]+)\s*\(", text)) - {"chunky_post_render_fn"})
+
+
+_lib: Optional[C.CDLL] = None
+POST_RENDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.chunky_last_error.restype = C.c_char_p
+        L.chunky_version.restype = C.c_char_p
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        sig = {
+            "chunky_device_count": [],
+            "chunky_device_name": [C.c_int, C.c_char_p, C.c_int],
+            "chunky_init": [C.c_int, C.POINTER(vp)],
+            "chunky_shutdown": [vp],
+            "chunky_scene_create": [vp, C.POINTER(vp)],
+            "chunky_scene_destroy": [vp],
+            "chunky_scene_set_octree": [vp, vp, i64, C.c_int],
+            "chunky_scene_load_octree": [vp, vp, i64, C.c_int, vp, i64],
+            "chunky_scene_set_palette": [vp, C.c_int, vp, i64],
+            "chunky_scene_set_bvh": [vp, C.c_int, vp, i64],
+            "chunky_scene_set_atlas": [vp, vp, C.c_int, C.c_int, C.c_int],
+            "chunky_scene_write_atlas_tile": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp],
+            "chunky_scene_set_sky": [vp, vp, C.c_int, C.c_int, f32],
+            "chunky_scene_set_sun": [vp, vp],
+            "chunky_render_create": [vp, vp, C.c_int, C.c_int, C.POINTER(vp)],
+            "chunky_render_destroy": [vp],
+            "chunky_render_set_camera": [vp, C.c_int, vp, i64],
+            "chunky_render_set_option": [vp, C.c_int, i32],
+            "chunky_render_set_shard": [vp, C.c_int, C.c_int, C.c_int],
+            "chunky_render_set_device_buffer": [vp, vp],
+            "chunky_render_device_buffer": [vp, C.POINTER(vp)],
+            "chunky_render_reset": [vp],
+            "chunky_render_passes": [vp, vp, C.c_int, C.c_int],
+            "chunky_render_sync": [vp],
+            "chunky_render_read": [vp, vp, i64],
+            "chunky_render_kernel_time": [vp, C.POINTER(f32), C.POINTER(C.c_int)],
+            "chunky_render_preview": [vp, vp],
+            "chunky_render_trace_records": [vp, i32, vp, C.c_int, vp, vp, vp],
+            "chunky_render_run": [vp, vp, C.POINTER(i32), i32, i32, POST_RENDER_FN, vp],
+            "chunky_java_random_ints": [i64, vp, C.c_int],
+            "chunky_selftest_math": [vp, C.c_int, C.c_int, vp, vp, vp],
+        }
+        for name, args in sig.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise ChunkyHipError(rc, (lib().chunky_last_error() or b"").decode("utf-8", "replace"))
+
+
+def ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def java_random_ints(n: int, seed: int = 0) -> np.ndarray:
+    out = np.zeros(n, np.int32)
+    check(lib().chunky_java_random_ints(seed, ptr(out), n))
+    return out

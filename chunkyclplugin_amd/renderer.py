@@ -1,0 +1,212 @@
+"""Host-side mirror of the reference's device-binding layer, on top of the C ABI.
+
+The reference's L2/L4 classes and their counterparts here:
+
+=====================================================  ==========================================
+reference (Java, JOCL)                                 this module (Python, ctypes -> libchunky_hip)
+=====================================================  ==========================================
+`RendererInstance.get()` (RendererInstance.java:23)    `RendererInstance.get(device)`
+`ClSceneLoader` getters (ClSceneLoader.java:95-150)     `HipSceneLoader.load_packed(scene)` + getters
+`ClCamera` (ClCamera.java:33-105)                       `HipPathTracingRenderer.set_camera`
+`OpenClPathTracingRenderer.render` (:54-191)            `HipPathTracingRenderer.render`
+`OpenClPreviewRenderer.render` (:47-115)                `HipPathTracingRenderer.preview`
+=====================================================  ==========================================
+
+What is NOT here: walking Chunky's `Scene` object (needs chunky-core; the Java side in
+INTEGRATION.md does that and hands the same packed arrays to the same C entry points).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import native
+from .native import check, ptr
+
+
+class RendererInstance:
+    """One GPU context per device index (the reference keeps a singleton for its one cl_device,
+    RendererInstance.java:23-28; `clDevice` index from PersistentSettings :33)."""
+
+    _instances = {}
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self._h = C.c_void_p()
+        check(native.lib().chunky_init(device, C.byref(self._h)))
+
+    @classmethod
+    def get(cls, device: int = 0) -> "RendererInstance":
+        if device not in cls._instances:
+            cls._instances[device] = RendererInstance(device)
+        return cls._instances[device]
+
+    @staticmethod
+    def device_count() -> int:
+        return native.lib().chunky_device_count()
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        check(native.lib().chunky_device_name(self.device, buf, 256))
+        return buf.value.decode()
+
+    def selftest_math(self, which: int, a, b=None) -> np.ndarray:
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(a if b is None else b, np.float32)
+        out = np.empty_like(a)
+        check(native.lib().chunky_selftest_math(self._h, which, a.size, ptr(a), ptr(b), ptr(out)))
+        return out
+
+    def close(self) -> None:
+        if self._h:
+            check(native.lib().chunky_shutdown(self._h))
+            self._h = C.c_void_p()
+            RendererInstance._instances.pop(self.device, None)
+
+
+class HipSceneLoader:
+    """Device copies of one packed scene — the buffer side of `ClSceneLoader`.
+
+    `load_packed` takes the arrays Chunky's packers produce (here: `scenes.PackedScene`) and uploads
+    them through the same entry points the JNI layer binds."""
+
+    def __init__(self, instance: Optional[RendererInstance] = None):
+        self.instance = instance or RendererInstance.get()
+        self._h = C.c_void_p()
+        check(native.lib().chunky_scene_create(self.instance._h, C.byref(self._h)))
+        self.packed = None
+
+    def load_packed(self, sc) -> bool:
+        L = native.lib()
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        tree = i32(sc.octree)
+        check(L.chunky_scene_set_octree(self._h, ptr(tree), tree.size, int(sc.octree_depth)))
+        for kind, arr in ((native.PALETTE_BLOCK, sc.block_palette), (native.PALETTE_MATERIAL, sc.material_palette),
+                          (native.PALETTE_AABB, sc.aabb_models), (native.PALETTE_QUAD, sc.quad_models),
+                          (native.PALETTE_TRIG, sc.bvh_trigs)):
+            a = i32(arr)
+            check(L.chunky_scene_set_palette(self._h, kind, ptr(a), a.size))
+        for which, arr in ((native.BVH_WORLD, sc.world_bvh), (native.BVH_ACTOR, sc.actor_bvh)):
+            a = i32(arr)
+            check(L.chunky_scene_set_bvh(self._h, which, ptr(a), a.size))
+        atlas = np.ascontiguousarray(sc.atlas, np.uint8)
+        layers, h, w, _ = atlas.shape
+        check(L.chunky_scene_set_atlas(self._h, ptr(atlas), w, h, layers))
+        sky = np.ascontiguousarray(sc.sky, np.uint8)
+        check(L.chunky_scene_set_sky(self._h, ptr(sky), sky.shape[1], sky.shape[0], float(sc.sky_intensity)))
+        sun = i32(sc.sun)
+        check(L.chunky_scene_set_sun(self._h, ptr(sun)))
+        self.packed = sc
+        return True
+
+    def load_octree(self, tree_data, depth: int, block_mapping) -> None:
+        """`ClSceneLoader.loadOctree` (ClSceneLoader.java:52-63): raw PackedOctree.treeData +
+        blockMapping, remapped natively."""
+        t = np.ascontiguousarray(tree_data, np.int32)
+        m = np.ascontiguousarray(block_mapping, np.int32)
+        check(native.lib().chunky_scene_load_octree(self._h, ptr(t), t.size, depth, ptr(m), m.size))
+
+    def close(self) -> None:
+        if self._h:
+            check(native.lib().chunky_scene_destroy(self._h))
+            self._h = C.c_void_p()
+
+
+class HipPathTracingRenderer:
+    """`OpenClPathTracingRenderer` for one image: ids, pass loop, read-back and merge."""
+
+    ID = "ChunkyClRenderer"  # OpenClPathTracingRenderer.java:33-46 (getId/getName/getDescription)
+
+    def __init__(self, scene_loader: HipSceneLoader, width: int, height: int):
+        self.scene_loader = scene_loader
+        self.width, self.height = width, height
+        self._h = C.c_void_p()
+        self.post_render: Optional[Callable[[], bool]] = None
+        check(native.lib().chunky_render_create(scene_loader.instance._h, scene_loader._h, width, height,
+                                                C.byref(self._h)))
+
+    # --- Renderer interface -----------------------------------------------------------------
+    def get_id(self) -> str:
+        return self.ID
+
+    def set_post_render(self, callback: Optional[Callable[[], bool]]) -> None:
+        self.post_render = callback
+
+    def auto_post_process(self) -> bool:
+        return False  # OpenClPathTracingRenderer.java:197-200
+
+    # --- camera / options -------------------------------------------------------------------
+    def set_camera(self, projector_type: int, settings) -> None:
+        s = np.ascontiguousarray(settings, np.float32)
+        check(native.lib().chunky_render_set_camera(self._h, int(projector_type), ptr(s), s.size))
+
+    def set_option(self, option: int, value) -> None:
+        if option == native.OPT_EMITTER_SCALE:
+            value = struct.unpack("<i", struct.pack("<f", float(value)))[0]
+        check(native.lib().chunky_render_set_option(self._h, option, int(value)))
+
+    def set_shard(self, rank: int, world: int, tile: int = 256) -> None:
+        check(native.lib().chunky_render_set_shard(self._h, rank, world, tile))
+
+    def set_device_buffer(self, device_ptr: Optional[int]) -> None:
+        check(native.lib().chunky_render_set_device_buffer(self._h, device_ptr))
+
+    def device_buffer(self) -> int:
+        p = C.c_void_p()
+        check(native.lib().chunky_render_device_buffer(self._h, C.byref(p)))
+        return p.value
+
+    # --- passes -------------------------------------------------------------------------------
+    def reset(self) -> None:
+        check(native.lib().chunky_render_reset(self._h))
+
+    def render_passes(self, seeds, first_buffer_spp: int = 0, sync: bool = True) -> None:
+        s = np.ascontiguousarray(seeds, np.int32)
+        check(native.lib().chunky_render_passes(self._h, ptr(s), s.size, first_buffer_spp))
+        if sync:
+            self.sync()
+
+    def sync(self) -> None:
+        check(native.lib().chunky_render_sync(self._h))
+
+    def read(self) -> np.ndarray:
+        out = np.empty(self.width * self.height * 3, np.float32)
+        check(native.lib().chunky_render_read(self._h, ptr(out), out.size))
+        return out
+
+    def kernel_time(self):
+        ms, n = C.c_float(), C.c_int()
+        check(native.lib().chunky_render_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def preview(self) -> np.ndarray:
+        out = np.empty(self.width * self.height, np.int32)
+        check(native.lib().chunky_render_preview(self._h, ptr(out)))
+        return out
+
+    def trace_records(self, seed: int, gids):
+        g = np.ascontiguousarray(gids, np.int32)
+        rec = np.zeros((g.size, native.MAX_TRACES), native.HIT_DTYPE)
+        cnt = np.zeros(g.size, np.int32)
+        rad = np.zeros((g.size, 3), np.float32)
+        check(native.lib().chunky_render_trace_records(self._h, int(seed), ptr(g), g.size, ptr(rec), ptr(cnt), ptr(rad)))
+        return rec, cnt, rad
+
+    def render(self, sample_buffer: np.ndarray, scene_spp: int, target_spp: int, merge_interval: int = 1024) -> int:
+        """The pass loop of OpenClPathTracingRenderer.render (:95-184) run natively; merges into the
+        caller's double sample buffer and returns the new scene.spp."""
+        assert sample_buffer.dtype == np.float64 and sample_buffer.size == self.width * self.height * 3
+        spp = C.c_int32(scene_spp)
+        cb = native.POST_RENDER_FN((lambda _u: 1 if self.post_render() else 0) if self.post_render else 0)
+        rc = native.lib().chunky_render_run(self._h, ptr(sample_buffer), C.byref(spp), target_spp, merge_interval, cb, None)
+        if rc not in (0, native.E_ABORTED):
+            check(rc)
+        return spp.value
+
+    def close(self) -> None:
+        if self._h:
+            check(native.lib().chunky_render_destroy(self._h))
+            self._h = C.c_void_p()

@@ -1,0 +1,164 @@
+/* chunky_hip.h — C ABI of the MI355X-native Chunky path-tracing hot path.
+ *
+ * This is the boundary a Chunky plugin binds instead of JOCL/OpenCL: plain pointers and sizes,
+ * no C++ or torch types.  Each entry point names the reference interface it replaces
+ * (paths relative to /root/reference/src/main/java/dev/thatredox/chunkynative/, "J/", and
+ * /root/reference/src/main/opencl/kernel/include/, "K/").  INTEGRATION.md shows the JNI stub a
+ * maintainer adds on the Java side.
+ *
+ * Conventions:
+ *   - every function returns 0 on success, a negative chunky_status on failure; the message is
+ *     available from chunky_last_error() on the calling thread.  Nothing aborts the process.
+ *   - host arrays are COPIED before the call returns (the reference creates every buffer with
+ *     CL_MEM_COPY_HOST_PTR / blocking writes: J/opencl/util/ClIntBuffer.java:23-25); the caller
+ *     keeps ownership.  Zero-length int arrays are legal (ClIntBuffer.java:15-18).
+ *   - handles may be destroyed from any thread, at most once (the reference frees from a GC
+ *     cleaner thread: J/util/NativeCleaner.java:45-53).  Calls on one context are serialised by
+ *     an internal mutex (the reference's renderLock, J/opencl/OpenClPathTracingRenderer.java:56).
+ *   - there is no CPU fallback: without a HIP device chunky_init fails with CHUNKY_E_NO_DEVICE.
+ */
+#ifndef CHUNKY_HIP_H
+#define CHUNKY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum chunky_status {
+    CHUNKY_OK = 0,
+    CHUNKY_E_INVALID = -1,    /* bad argument / handle */
+    CHUNKY_E_NO_DEVICE = -2,  /* no HIP device, or device index out of range */
+    CHUNKY_E_HIP = -3,        /* a HIP runtime call failed (message has the HIP error string) */
+    CHUNKY_E_STATE = -4,      /* call sequence error (e.g. render before a scene is complete) */
+    CHUNKY_E_ABORTED = -5     /* the postRender callback asked to stop */
+} chunky_status;
+
+typedef struct chunky_ctx chunky_ctx;        /* one GPU: J/opencl/renderer/RendererInstance.java */
+typedef struct chunky_scene chunky_scene;    /* device copies of the packed scene: J/opencl/renderer/ClSceneLoader.java */
+typedef struct chunky_render chunky_render;  /* one render target + camera: OpenClPathTracingRenderer.render locals */
+
+/* ---- device (replaces RendererInstance.java:31-110: platform/device enumeration, context, queue) */
+int chunky_device_count(void);
+int chunky_device_name(int device, char* buf, int buf_len);
+int chunky_init(int device, chunky_ctx** out);
+int chunky_shutdown(chunky_ctx* ctx);
+const char* chunky_last_error(void);
+/* Library identity: "chunky-hip <version> gfx950". */
+const char* chunky_version(void);
+
+/* ---- scene upload (replaces the clCreateBuffer/clCreateImage sites of ClSceneLoader.java:52-150,
+ *      ClIntBuffer.java:14-26, ClTextureLoader.java:50-67, ClSky.java:28-61) */
+int chunky_scene_create(chunky_ctx* ctx, chunky_scene** out);
+int chunky_scene_destroy(chunky_scene* scene);
+
+/* octreeData after the leaf remap of ClSceneLoader.java:52-63 + octreeDepth (getOctreeData/getOctreeDepth) */
+int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree, int64_t n_ints, int depth);
+/* Same, from Chunky's raw PackedOctree.treeData + blockMapping: performs the remap
+ * `i>0 || -i>=len ? i : -blockMapping[-i]` of ClSceneLoader.java:56-58 on the way in (a22). */
+int chunky_scene_load_octree(chunky_scene* scene, const int32_t* tree_data, int64_t n_ints, int depth,
+                             const int32_t* block_mapping, int64_t n_mapping);
+
+typedef enum chunky_palette {
+    CHUNKY_PALETTE_BLOCK = 0,    /* getBlockPalette():    2 ints/block      (PackedBlock.java:80-85) */
+    CHUNKY_PALETTE_MATERIAL = 1, /* getMaterialPalette(): 6 ints/material   (PackedMaterial.java:89-100) */
+    CHUNKY_PALETTE_AABB = 2,     /* getAabbPalette():     1+13n ints/model  (PackedAabbModel.java:41-47) */
+    CHUNKY_PALETTE_QUAD = 3,     /* getQuadPalette():     1+15n ints/model  (PackedQuadModel.java:39-45) */
+    CHUNKY_PALETTE_TRIG = 4      /* getTrigPalette():     1+20n ints/leaf   (PackedTriangleModel.java:28-34) */
+} chunky_palette;
+int chunky_scene_set_palette(chunky_scene* scene, int kind, const int32_t* data, int64_t n_ints);
+
+typedef enum chunky_bvh { CHUNKY_BVH_WORLD = 0, CHUNKY_BVH_ACTOR = 1 } chunky_bvh;
+/* getWorldBvh()/getActorBvh(): 7 ints/node (PackedBvhNode.java:16-31); {0, NaN x 6} = empty */
+int chunky_scene_set_bvh(chunky_scene* scene, int which, const int32_t* nodes, int64_t n_ints);
+
+/* Texture atlas (getTexturePalette().getAtlas()): RGBA8, [layer][y][x][4].  gfx950 has no image
+ * instructions, so the atlas is a flat buffer; width/height need only cover the occupied tiles
+ * (the reference allocates 8192x8192 per layer, ClTextureLoader.java:50-58; locations are
+ * identical).  set_atlas allocates (and zero-fills when rgba == NULL); write_atlas_tile mirrors the
+ * per-texture clEnqueueWriteImage of ClTextureLoader.java:61-66. */
+int chunky_scene_set_atlas(chunky_scene* scene, const uint8_t* rgba, int width, int height, int layers);
+int chunky_scene_write_atlas_tile(chunky_scene* scene, int x, int y, int layer, int w, int h, const uint8_t* rgba);
+/* getSky(): skyTexture RGBA8 [h][w][4] + skyIntensity (ClSky.java:28-30,43-61) */
+int chunky_scene_set_sky(chunky_scene* scene, const uint8_t* rgba, int width, int height, float intensity);
+/* getSun(): flags, textureSize, textureLocation, intensity, altitude, azimuth (PackedSun.java:32-41) */
+int chunky_scene_set_sun(chunky_scene* scene, const int32_t sun[6]);
+
+/* ---- render target (replaces the buffers and the launch of OpenClPathTracingRenderer.java:67-141) */
+int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int width, int height, chunky_render** out);
+int chunky_render_destroy(chunky_render* r);
+/* ClCamera (ClCamera.java:33-70): projector_type 0 = pinhole with 15 floats; -1 = pre-generated rays,
+ * width*height*6 floats (ClCamera.java:72-105); any other value is rejected. */
+int chunky_render_set_camera(chunky_render* r, int projector_type, const float* settings, int64_t n_floats);
+
+typedef enum chunky_option {
+    CHUNKY_OPT_DRAW_DEPTH = 0,      /* int, default 256  (K/rayTracer.cl:94) */
+    CHUNKY_OPT_MAX_DEPTH = 1,       /* int, default 5    (K/rayTracer.cl:107) */
+    CHUNKY_OPT_EMITTER_SCALE = 2,   /* float bits, default 13.0f (K/rayTracer.cl:99) */
+    CHUNKY_OPT_KERNEL = 3           /* int: kernel variant, 0 = default */
+} chunky_option;
+int chunky_render_set_option(chunky_render* r, int option, int32_t value);
+
+/* Multi-GPU image-tile ownership (no reference counterpart — the reference is single-device):
+ * pixel indices are cut into tiles of `tile` consecutive gids, tile t belongs to rank t % world.
+ * A rank renders only its tiles; every other pixel of its buffer stays 0, so a SUM reduce over
+ * ranks (one RCCL collective per read-back) reproduces the 1-GPU image bit for bit. */
+int chunky_render_set_shard(chunky_render* r, int rank, int world, int tile);
+/* Use a caller-owned device buffer (3*width*height floats) as the framebuffer, e.g. a torch tensor
+ * that torch.distributed reduces over RCCL.  NULL returns to the internal buffer. */
+int chunky_render_set_device_buffer(chunky_render* r, void* device_ptr);
+int chunky_render_device_buffer(chunky_render* r, void** device_ptr);
+/* Zero the device framebuffer (the reference uploads a zeroed passBuffer, OpenClPathTracingRenderer.java:61,71). */
+int chunky_render_reset(chunky_render* r);
+
+/* Enqueue n passes: pass k uses seeds[k] as *randomSeed and first_buffer_spp + k as *bufferSpp
+ * (OpenClPathTracingRenderer.java:106-141; n = 1 reproduces the reference's one launch per spp).
+ * Asynchronous; chunky_render_sync / chunky_render_read wait. */
+int chunky_render_passes(chunky_render* r, const int32_t* seeds, int n, int first_buffer_spp);
+int chunky_render_sync(chunky_render* r);
+/* Blocking read-back of the running-mean buffer, 3*width*height floats (clEnqueueReadBuffer,
+ * OpenClPathTracingRenderer.java:164-166). */
+int chunky_render_read(chunky_render* r, float* out, int64_t n_floats);
+/* Device time of the render kernels enqueued since the last call, from HIP events on the stream the
+ * kernels run on: total milliseconds and number of launches. */
+int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches);
+
+/* Preview kernel (K/rayTracer.cl:115-217; OpenClPreviewRenderer.java:47-115): width*height ARGB ints. */
+int chunky_render_preview(chunky_render* r, int32_t* argb_out);
+
+/* Parity instrument: for each gid, the outcome of every closestIntersect of one sample (main and
+ * shadow traces in call order) and the sample's radiance. */
+typedef struct chunky_hit_record {
+    int32_t hit;       /* closestIntersect result */
+    int32_t material;  /* record.material: block-palette pointer of the octree hit */
+    float distance;
+    float normal[3];
+    float color[4];
+    float emittance;
+    float point[3];
+} chunky_hit_record;
+#define CHUNKY_MAX_TRACES 10
+int chunky_render_trace_records(chunky_render* r, int32_t seed, const int32_t* gids, int n,
+                                chunky_hit_record* records /* n*CHUNKY_MAX_TRACES */, int32_t* counts /* n */,
+                                float* radiance /* 3n */);
+
+/* ---- host pass loop (replaces OpenClPathTracingRenderer.render, J/opencl/OpenClPathTracingRenderer.java:54-191):
+ * seeds from java.util.Random(0).nextInt(), bufferSpp restarting at 0 after each read-back, merge
+ * sample = (sample*sampSpp + pass*passSpp) / (sampSpp+passSpp) in double (:167-173).
+ * `sample_buffer` is Chunky's double[3*W*H]; `*scene_spp` its scene.spp (in/out).  `post_render`
+ * (may be NULL) is polled at least every 100 ms and at every merge; non-zero stops the loop
+ * (:153-157,163).  `merge_interval` = passes per read-back (the reference uses 1024, :158). */
+typedef int (*chunky_post_render_fn)(void* user);
+int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
+                      int32_t merge_interval, chunky_post_render_fn post_render, void* user);
+/* The seed stream itself: first n values of new java.util.Random(seed).nextInt(). */
+int chunky_java_random_ints(int64_t seed, int32_t* out, int n);
+
+/* ---- self test: evaluate the rt_math.h contract on the device (bit-compared with the host by tests) */
+int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const float* a, const float* b, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHUNKY_HIP_H */

@@ -201,6 +201,7 @@ void intersectSky(RefRecord*, const ShimImage*, RefSun*, const ShimImage*, float
 void applyRayColor(RefRecord*, float);
 bool Sun_sampleDirection(RefSun*, RefRecord*, unsigned*);
 bool nextPath(RefRecord*, unsigned*, int);
+RefRecord IntersectionRecord_copy(RefRecord*);
 unsigned Random_nextState(unsigned*);
 float Random_nextFloat(unsigned*);
 void Camera_pinHole(float, float, unsigned*, cl_float3*, cl_float3*, const float*);
@@ -347,7 +348,7 @@ int ref_trace_records(const OracleScene* s, int seed, int gid, OracleHit* out, f
         }
         applyRayColor(&rec, 13.0f);
         if (Sun_sampleDirection(&sun, &rec, &state)) {
-            RefRecord sr = rec; /* IntersectionRecord_copy; its point field is dead (wavefront.h:73) */
+            RefRecord sr = IntersectionRecord_copy(&rec);
             bool sh = closestIntersect(&sr, &oct, &bp, &atlas, 256, &wb, &ab);
             put(sh, sr);
             if (!sh) intersectSky(&sr, &atlas, &sun, &sky, s->sky_intensity);

@@ -1,0 +1,62 @@
+"""The named small scenes behind tests/golden/*.npz (inputs are regenerated from seeds; outputs
+were produced by the reference kernel itself, see tests/golden/generate.py)."""
+import dataclasses
+import hashlib
+
+import numpy as np
+
+from chunkyclplugin_amd import scenes
+
+W, H = 64, 48
+N_PASSES = 3
+
+
+def _outdoor():
+    return scenes.outdoor_world(chunks=2, height=48, seed=101, width=W, img_height=H, aabb_frac=0.08,
+                                quad_frac=0.05, emitters=0.02)
+
+
+def make(name: str) -> scenes.PackedScene:
+    if name == "outdoor":
+        return _outdoor()
+    if name == "outdoor_nosun":
+        return dataclasses.replace(_outdoor(), sun=scenes.pack_sun(0.6, 1.2, 1.25, False))
+    if name == "entities":
+        sc = _outdoor()
+        return scenes.add_entities(sc, 600, seed=5, actor_tris=120, region=((2, 20, 2), (30, 44, 30)))
+    if name == "dof":
+        sc = _outdoor()
+        cam = sc.camera.copy()
+        cam[12], cam[13] = 0.08, 18.0
+        return dataclasses.replace(sc, camera=cam)
+    if name == "pregen":
+        sc = _outdoor()
+        rng = np.random.default_rng(9)
+        rays = np.zeros((W * H, 6), np.float32)
+        rays[:, :3] = sc.camera[:3]
+        d = rng.normal(size=(W * H, 3))
+        d[:, 1] -= 0.8
+        rays[:, 3:] = d
+        return dataclasses.replace(sc, camera=rays.reshape(-1), projector_type=-1)
+    if name == "inside":
+        sc = _outdoor()
+        return dataclasses.replace(sc, camera=scenes.look_at_camera((10.3, 9.2, 12.1), (20, 14, 20), 90.0))
+    if name == "indoor":
+        return scenes.indoor_room(size=24, seed=7, width=W, img_height=H, emitter_frac=0.03)
+    if name == "indoor_sun":
+        sc = scenes.indoor_room(size=24, seed=7, width=W, img_height=H, emitter_frac=0.03)
+        return dataclasses.replace(sc, sun=scenes.pack_sun(0.6, 1.2, 1.25, True))
+    raise KeyError(name)
+
+
+NAMES = ["outdoor", "outdoor_nosun", "entities", "dof", "pregen", "inside", "indoor", "indoor_sun"]
+RECORD_GIDS = np.arange(0, W * H, 37, dtype=np.int32)
+
+
+def input_digest(sc: scenes.PackedScene) -> str:
+    h = hashlib.sha256()
+    for f in ("octree", "block_palette", "material_palette", "aabb_models", "quad_models", "world_bvh",
+              "actor_bvh", "bvh_trigs", "atlas", "sky", "sun", "camera"):
+        h.update(np.ascontiguousarray(getattr(sc, f)).tobytes())
+    h.update(repr((sc.octree_depth, float(sc.sky_intensity), sc.projector_type, sc.width, sc.height)).encode())
+    return h.hexdigest()

@@ -1,0 +1,45 @@
+"""The C-ABI library loads and exports every symbol include/chunky_hip.h declares; its host-only
+entry points behave; without a GPU the device path fails loudly instead of falling back."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from chunkyclplugin_amd import native, scenes
+
+
+def test_exports_every_declared_symbol():
+    L = native.lib()
+    names = native.declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/chunky_hip.h but not exported"
+    assert b"gfx950" in L.chunky_version()
+
+
+def test_java_seed_stream_native():
+    want = [-1155484576, -723955400, 1033096058, -1690734402, -1557280266, 1327362106, -1930858313, 502539523]
+    assert native.java_random_ints(8).tolist() == want
+    assert native.java_random_ints(100, seed=12345).tolist() == scenes.java_random_ints(100, seed=12345).tolist()
+
+
+def test_null_handles_are_errors_not_crashes():
+    L = native.lib()
+    assert L.chunky_shutdown(None) == native.E_INVALID
+    assert L.chunky_scene_destroy(None) == native.E_INVALID
+    assert L.chunky_render_sync(None) == native.E_INVALID
+    assert L.chunky_init(0, None) == native.E_INVALID
+    assert b"NULL" in L.chunky_last_error()
+
+
+def test_no_device_means_error_not_fallback():
+    L = native.lib()
+    if L.chunky_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    h = C.c_void_p()
+    assert L.chunky_init(0, C.byref(h)) == native.E_NO_DEVICE
+    assert not h.value
+    assert b"no CPU fallback" in L.chunky_last_error()
+    from chunkyclplugin_amd.renderer import RendererInstance
+    with pytest.raises(native.ChunkyHipError):
+        RendererInstance(0)

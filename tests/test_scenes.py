@@ -1,0 +1,77 @@
+"""Host-side packers/generators (wire formats of SURVEY.md Appendix A)."""
+import numpy as np
+
+from chunkyclplugin_amd import scenes
+
+
+def lookup(tree, depth, x, y, z):
+    """Octree_get (K/octree.h:23-39) in Python."""
+    level, data = depth, int(tree[0])
+    while data > 0:
+        level -= 1
+        data = int(tree[data + ((((x >> level) & 1) << 2) | (((y >> level) & 1) << 1) | ((z >> level) & 1))])
+    return -data, level
+
+
+def test_octree_roundtrip_and_merge():
+    rng = np.random.default_rng(0)
+    depth, S = 4, 16
+    t = np.zeros((S, S, S), np.int32)
+    t[:8, :8, :8] = 3                      # mergeable 8^3 region
+    t[8:, 8:, 8:] = rng.integers(0, 5, size=(8, 8, 8))
+    t[12, 3, 3] = scenes.ANY_TYPE
+    for order in ("bfs", "dfs"):
+        tree = scenes.build_octree(t, depth, order)
+        assert (tree.size - 1) % 8 == 0
+        for _ in range(300):
+            x, y, z = rng.integers(0, S, size=3)
+            v, level = lookup(tree, depth, int(x), int(y), int(z))
+            want = int(t[x, y, z])
+            assert v == (scenes.ANY_TYPE if want == scenes.ANY_TYPE else 2 * want)
+        v, level = lookup(tree, depth, 1, 2, 3)
+        assert (v, level) == (6, 3)        # merged into one level-3 leaf
+    a, b = scenes.build_octree(t, depth, "bfs"), scenes.build_octree(t, depth, "dfs")
+    assert a.size == b.size
+
+
+def test_atlas_first_fit_and_location_bits():
+    ab = scenes.AtlasBuilder(4, 4)
+    rng = np.random.default_rng(1)
+    ids = [ab.add(scenes.noise_texture(rng, (10 * i, 20, 30))) for i in range(5)]
+    big = ab.add(scenes.noise_texture(rng, (200, 200, 200), size=32))
+    atlas, recs = ab.build()
+    assert atlas.shape == (1, 64, 64, 4)
+    size, loc = recs[big]
+    assert size == (32 << 16) | 32 and loc == 0          # largest first, at tile (0,0), layer 0
+    # x outer, y inner: after the 2x2 tile, the next free tiles are (0,2), (0,3), (1,2)...
+    assert [(recs[i][1] >> 22) & 0x1FF for i in ids[:3]] == [0, 0, 1]
+    assert [(recs[i][1] >> 13) & 0x1FF for i in ids[:3]] == [2, 3, 2]
+    for i in ids:
+        size, loc = recs[i]
+        x, y = ((loc >> 22) & 0x1FF) * 16, ((loc >> 13) & 0x1FF) * 16
+        assert (atlas[0, y:y + 16, x:x + 16] == ab._tex[i]).all()
+
+
+def test_bvh_layout():
+    sc = scenes.add_entities(scenes.tiny_scene(entities=0), 64, actor_tris=16)
+    for nodes in (sc.world_bvh, sc.actor_bvh):
+        n = nodes.reshape(-1, 7)
+        inner = n[:, 0] > 0
+        assert (n[inner, 0] % 7 == 0).all() and (n[inner, 0] < nodes.size).all()
+        leaves = -n[~inner, 0]
+        assert (leaves >= 0).all() and (leaves < sc.bvh_trigs.size).all()
+        cnt = sc.bvh_trigs[leaves]
+        assert (cnt >= 1).all() and (cnt <= 4).all()
+    e = scenes.empty_bvh()
+    assert e[0] == 0 and np.isnan(e[1:].view(np.float32)).all()
+
+
+def test_sun_and_camera_packing():
+    sun = scenes.pack_sun(0.6, 1.2, 1.25, True, (0x200020, 5))
+    assert sun[0] == 1 and sun[1] == 0x200020 and sun[2] == 5
+    assert np.allclose(sun[3:].view(np.float32), [1.25, 0.6, 1.2])
+    cam = scenes.look_at_camera((1, 2, 3), (4, 2, 7))
+    assert cam.shape == (15,)
+    M = cam[3:12].reshape(3, 3)
+    assert np.allclose(M @ M.T, np.eye(3), atol=1e-6)
+    assert np.allclose(M[:, 2], np.array([3, 0, 4]) / 5, atol=1e-6)   # third column = forward
