@@ -121,8 +121,8 @@ DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O,
             // copy of the main record (distance included), traced along the shared ray from
             // `point` with no offset.
             d = sun_sample(S, rng);
+            h.emittance = rt_fabs(dot(d, h.normal));  // written to the main record, then copied (K/sky.h:90)
             Hit sh = h;
-            sh.emittance = rt_fabs(dot(d, h.normal));
             f3 sp = h.normal;  // the copy's dead point = normal (K/wavefront.h:73)
             bool shadowed = closest_hit(S, o, d, O.draw_depth, sh, sp, stack);
             if (RECORD) put_record(rec_out, nrec, shadowed, sh, sp);

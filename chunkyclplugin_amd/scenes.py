@@ -683,3 +683,52 @@ def tiny_scene(seed: int = 3, size: int = 16, width: int = 48, height: int = 32,
         sc = add_entities(sc, entities, seed=seed + 1, actor_tris=entities // 2,
                           region=((1, 0.35 * S, 1), (size - 1, 0.75 * S, size - 1)))
     return sc
+
+
+# ---------------------------------------------------------------------------------------- cache
+_ARRAY_FIELDS = ("octree", "block_palette", "material_palette", "aabb_models", "quad_models", "world_bvh",
+                 "actor_bvh", "bvh_trigs", "atlas", "sky", "sun", "camera")
+
+
+def save_scene(sc: PackedScene, path: str) -> None:
+    import os
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    tmp = path + f".{os.getpid()}.tmp.npz"
+    np.savez(tmp, meta=np.array([sc.octree_depth, sc.projector_type, sc.width, sc.height], np.int64),
+             sky_intensity=np.float64(sc.sky_intensity), name=np.array(sc.name),
+             **{f: getattr(sc, f) for f in _ARRAY_FIELDS})
+    os.replace(tmp, path)
+
+
+def load_scene(path: str) -> PackedScene:
+    z = np.load(path)
+    depth, proj, w, h = (int(v) for v in z["meta"])
+    return PackedScene(octree_depth=depth, projector_type=proj, width=w, height=h,
+                       sky_intensity=float(z["sky_intensity"]), name=str(z["name"]),
+                       **{f: z[f] for f in _ARRAY_FIELDS})
+
+
+def cached_outdoor_world(**kw) -> PackedScene:
+    """outdoor_world(**kw) through an on-disk cache (.scene_cache/ next to the package): the
+    32x32-chunk world takes ~30 s of numpy to generate and is byte-identical every time."""
+    import hashlib
+    import inspect
+    import os
+    sig = inspect.signature(outdoor_world)
+    bound = sig.bind(**kw)
+    bound.apply_defaults()
+    src = inspect.getsource(outdoor_world) + inspect.getsource(build_octree) + inspect.getsource(hide_interior)
+    key = hashlib.sha256((repr(sorted(bound.arguments.items())) + src).encode()).hexdigest()[:16]
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".scene_cache")
+    path = os.path.join(root, f"outdoor_{key}.npz")
+    if os.path.exists(path):
+        try:
+            return load_scene(path)
+        except Exception:
+            pass
+    sc = outdoor_world(**kw)
+    try:
+        save_scene(sc, path)
+    except OSError:
+        pass
+    return sc

@@ -162,6 +162,19 @@ class PortLib(_Lib):
         self.lib.port_counters_reset.restype = None
         self.lib.port_counters_read.argtypes = [C.c_void_p]
         self.lib.port_counters_enable.argtypes = [C.c_int]
+        self.lib.port_render_gids.argtypes = [C.POINTER(OracleScene), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_int64, C.c_void_p, C.c_int]
+
+    def render_gids(self, sc, seeds, gids, first_spp: int = 0, res: Optional[np.ndarray] = None,
+                    threads: int = 8) -> np.ndarray:
+        h = sc if isinstance(sc, SceneHandle) else SceneHandle(sc)
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        gids = np.ascontiguousarray(gids, np.int32)
+        if res is None:
+            res = np.zeros(3 * h.width * h.height, np.float32)
+        self.lib.port_render_gids(C.byref(h.struct), _ptr(seeds), len(seeds), first_spp, _ptr(gids), gids.size,
+                                  _ptr(res), threads)
+        return res
 
     def counters(self, enable: Optional[bool] = None, reset: bool = False) -> dict:
         if enable is not None:

@@ -706,6 +706,34 @@ int port_render_passes(const OracleScene* s, const int32_t* seeds, int n_passes,
     return 0;
 }
 
+/* Same, over an explicit list of pixel indices (bench.py samples whole rows of a large image). */
+int port_render_gids(const OracleScene* s, const int32_t* seeds, int n_passes, int first_spp, const int32_t* gids,
+                     int64_t n_gids, float* res, int threads) {
+    Sun sun = sun_new(s->sun);
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        Counters local;
+        memset(&local, 0, sizeof local);
+        t_ctr = g_count_enabled ? &local : 0;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t i = 0; i < n_gids; i++) {
+            int gid = gids[i];
+            float* px = res + 3 * (int64_t)gid;
+            for (int k = 0; k < n_passes; k++) {
+                int spp = first_spp + k;
+                v3 c = trace_sample(s, &sun, seeds[k], gid, 0, 0);
+                px[0] = (px[0] * spp + c.x) / (spp + 1);
+                px[1] = (px[1] * spp + c.y) / (spp + 1);
+                px[2] = (px[2] * spp + c.z) / (spp + 1);
+            }
+        }
+        if (g_count_enabled) counters_merge(&local);
+        t_ctr = 0;
+    }
+    return 0;
+}
+
 int port_trace_records(const OracleScene* s, int seed, int gid, OracleHit* out, float* radiance) {
     Sun sun = sun_new(s->sun);
     int n = 0;

@@ -61,6 +61,9 @@ def test_device_math_bit_equals_host(gpu_instance, port, which):
     if which != 13:
         a[:121] = np.repeat(specials, 11)
         b[:121] = np.tile(specials, 11)
+    if which in (0, 1):
+        # rt_sincos is specified for |x| <= 1e4 (rt_math.h): beyond that the quadrant index overflows
+        a = np.where(np.abs(a) > 1e4, np.float32(1e4), a).astype(np.float32)
     dev = gpu_instance.selftest_math(which, a, b)
     if which <= 9:
         host = port.math(which, a, b)
@@ -256,7 +259,7 @@ def test_render_run_matches_reference_host_loop(gpu_instance, port):
 def test_full_size_properties(gpu_instance):
     """BASELINE config 3 at full resolution: the oracle is too slow here, so check properties:
     determinism, pass-order independence of per-pass images, tiles == full, running-mean identity."""
-    sc = scenes.outdoor_world(chunks=32, height=256)
+    sc = scenes.cached_outdoor_world(chunks=32, height=256)
     loader, r = make_renderer(gpu_instance, sc)
     seeds = scenes.java_random_ints(2)
     r.render_passes(seeds)
