@@ -16,6 +16,7 @@
 #include "../../include/chunky_hip.h"
 #include "kernels.hpp"
 #include "rt_device.hpp"
+#include "widetree.hpp"
 
 using namespace chunky;
 
@@ -73,7 +74,8 @@ struct DevBuf {
 
 struct chunky_scene {
     chunky_ctx* ctx = nullptr;
-    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky;
+    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide;
+    WideTree wide_meta;  // data vector released after upload; nlev == 0 when absent
     int octree_depth = -1;
     int atlas_w = 0, atlas_h = 0, atlas_layers = 0;
     int sky_w = 0, sky_h = 0;
@@ -205,6 +207,19 @@ extern "C" int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree,
     }
     HIP_TRY(scene->octree.upload(tree, (size_t)n * 4, scene->ctx->stream));
     scene->octree_depth = depth;
+    // wide re-layout for the fast lookup; scenes it cannot express keep the reference layout only
+    scene->wide.release();
+    scene->wide_meta = WideTree();
+    int bits[kWideMaxLevels];
+    int nlev = default_wide_levels(depth, bits);
+    const char* why = "";
+    WideTree wt;
+    if (build_wide_tree(tree, n, depth, bits, nlev, &wt, &why)) {
+        HIP_TRY(scene->wide.upload(wt.data.data(), wt.data.size() * 4, scene->ctx->stream));
+        wt.data.clear();
+        wt.data.shrink_to_fit();
+        scene->wide_meta = wt;
+    }
     return CHUNKY_OK;
 }
 
@@ -364,6 +379,12 @@ static int scene_view(const chunky_scene* s, SceneView* v) {
     v->sun_radius_cos = rt_cos(0.03f);
     v->world_bvh_empty = (s->world_empty || !s->world_bvh.p) ? 1 : 0;
     v->actor_bvh_empty = (s->actor_empty || !s->actor_bvh.p) ? 1 : 0;
+    v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;
+    v->wide_nlev = s->wide_meta.nlev;
+    for (int i = 0; i < 6; i++) {
+        v->wide_shift[i] = s->wide_meta.shift[i];
+        v->wide_bits[i] = s->wide_meta.bits[i];
+    }
     return CHUNKY_OK;
 }
 
@@ -564,7 +585,7 @@ extern "C" int chunky_render_preview(chunky_render* r, int32_t* argb_out) {
     size_t bytes = (size_t)r->width * r->height * 4;
     HIP_TRY(hipMalloc(&out.p, bytes));
     out.bytes = bytes;
-    HIP_TRY(launch_preview(S, r->cam, r->opts, (int*)out.p, r->ctx->stream));
+    HIP_TRY(launch_preview(r->kernel_variant, S, r->cam, r->opts, (int*)out.p, r->ctx->stream));
     HIP_TRY(hipMemcpyAsync(argb_out, out.p, bytes, hipMemcpyDeviceToHost, r->ctx->stream));
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
     return CHUNKY_OK;
@@ -587,7 +608,7 @@ extern "C" int chunky_render_trace_records(chunky_render* r, int32_t seed, const
     HIP_TRY(hipMalloc(&dc.p, (size_t)n * 4));
     HIP_TRY(hipMalloc(&dq.p, (size_t)n * 12));
     HIP_TRY(hipMemsetAsync(dr.p, 0, (size_t)n * kMaxTraces * sizeof(HitRecord), st));
-    HIP_TRY(launch_trace_records(S, r->cam, r->opts, seed, (const int*)dg.p, n, (HitRecord*)dr.p, (int*)dc.p, (float*)dq.p, st));
+    HIP_TRY(launch_trace_records(r->kernel_variant, S, r->cam, r->opts, seed, (const int*)dg.p, n, (HitRecord*)dr.p, (int*)dc.p, (float*)dq.p, st));
     HIP_TRY(hipMemcpyAsync(records, dr.p, (size_t)n * kMaxTraces * sizeof(HitRecord), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(counts, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(radiance, dq.p, (size_t)n * 12, hipMemcpyDeviceToHost, st));
@@ -663,6 +684,41 @@ extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_
         logical_spp += buffer_spp;                                            // :178
         if (stop) return fail(CHUNKY_E_ABORTED, "stopped by postRender");
         // bufferSppReal = 0 (:170): the next pass runs with spp = 0, i.e. (mean*0 + c)/1 — no reset needed
+    }
+    return CHUNKY_OK;
+}
+
+// ------------------------------------------------------------------------------------ wide tree hook
+extern "C" int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int depth, const int32_t* level_bits,
+                                      int n_levels, const int32_t* xyz, int n, int32_t* data_out, int32_t* level_out,
+                                      int64_t* n_entries) {
+    if (int rc = check_ints(tree, n_ints, "widetree_lookup")) return rc;
+    if (n_ints < 1 || n < 0 || (n > 0 && (!xyz || !data_out || !level_out))) return fail(CHUNKY_E_INVALID, "widetree_lookup: bad arguments");
+    int bits[kWideMaxLevels];
+    int nlev;
+    if (level_bits) {
+        if (n_levels < 1 || n_levels > kWideMaxLevels) return fail(CHUNKY_E_INVALID, "widetree_lookup: 1..%d levels", kWideMaxLevels);
+        nlev = n_levels;
+        for (int i = 0; i < nlev; i++) bits[i] = level_bits[i];
+    } else {
+        nlev = default_wide_levels(depth, bits);
+    }
+    WideTree wt;
+    const char* why = "";
+    if (!build_wide_tree(tree, n_ints, depth, bits, nlev, &wt, &why)) return fail(CHUNKY_E_INVALID, "wide tree: %s", why);
+    if (n_entries) *n_entries = (int64_t)wt.data.size();
+    for (int i = 0; i < n; i++) {
+        int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (((x | y | z) >> depth) != 0) return fail(CHUNKY_E_INVALID, "widetree_lookup: cell outside the world");
+        int32_t e = 0;
+        for (int l = 0; l < wt.nlev && e >= 0; l++) {
+            const int sh = wt.shift[l], b = wt.bits[l], m = (1 << b) - 1;
+            e = (int32_t)wt.data[(size_t)e + (size_t)(((((x >> sh) & m) << b) | ((y >> sh) & m)) << b | ((z >> sh) & m))];
+        }
+        if (e >= 0) return fail(CHUNKY_E_INVALID, "wide tree: lookup did not end in a leaf");
+        level_out[i] = (e >> 27) & 15;
+        uint32_t code = (uint32_t)e & kWideAny;
+        data_out[i] = code == kWideAny ? 0x7FFFFFFE : (int32_t)code;
     }
     return CHUNKY_OK;
 }

@@ -21,9 +21,41 @@ struct LdsStack {
     DEV int pop(int slot) { return base[slot * stride]; }
 };
 
-// Octree_octreeIntersect — K/octree.h:41-109.  Root-restart descent, leaf-exit march.
+// Leaf lookup of K/octree.h:81-89: cell (bx,by,bz) -> block pointer `data` and leaf `level`.
+// WIDE = false walks the reference layout from the root, one bit per level; WIDE = true walks the
+// wide re-layout (widetree.hpp), bits[i] bits per level — same (data, level) for every cell.
+template <bool WIDE>
+DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level) {
+    if (!WIDE) {
+        const int* __restrict__ tree = S.octree;
+        level = S.octree_depth;
+        data = tree[0];
+        while (data > 0) {
+            level--;
+            data = tree[data + ((((bx >> level) & 1) << 2) | (((by >> level) & 1) << 1) | ((bz >> level) & 1))];
+        }
+        data = -data;
+    } else {
+        const uint32_t* __restrict__ tree = S.wide;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            if (i < S.wide_nlev && e >= 0) {
+                const int sh = S.wide_shift[i], b = S.wide_bits[i];
+                const unsigned ix = __builtin_amdgcn_ubfe((unsigned)bx, sh, b), iy = __builtin_amdgcn_ubfe((unsigned)by, sh, b),
+                               iz = __builtin_amdgcn_ubfe((unsigned)bz, sh, b);
+                e = (int)tree[e + (int)((((ix << b) | iy) << b) | iz)];
+            }
+        }
+        level = (e >> 27) & 15;
+        unsigned code = (unsigned)e & 0x7FFFFFFu;
+        data = code == 0x7FFFFFFu ? kAnyType : (int)code;
+    }
+}
+
+// Octree_octreeIntersect — K/octree.h:41-109.  Leaf-exit march.
+template <bool WIDE>
 DEV bool octree_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h) {
-    const int* __restrict__ tree = S.octree;
     const int depth = S.octree_depth;
     float dist_march = 0;
     f3 inv = rcp3(d);
@@ -40,14 +72,9 @@ DEV bool octree_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h) {
         f3 pos = o + d * dist_march;
         f3 po = pos + off;
         int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
-        if (((bx >> depth) != 0) | ((by >> depth) != 0) | ((bz >> depth) != 0)) return false;
-        int level = depth;
-        int data = tree[0];
-        while (data > 0) {
-            level--;
-            data = tree[data + ((((bx >> level) & 1) << 2) | (((by >> level) & 1) << 1) | ((bz >> level) & 1))];
-        }
-        data = -data;
+        if (((bx | by | bz) >> depth) != 0) return false;  // any coordinate outside [0, 2^depth)
+        int level, data;
+        leaf_lookup<WIDE>(S, bx, by, bz, data, level);
         if (data != 0) {  // ray->material is always 0 (K/wavefront.h:34, K/octree.h:92)
             float dist = block_hit(S, data, bx, by, bz, pos, d, inv, h);
             if (dist == dist) {
@@ -67,8 +94,9 @@ DEV bool octree_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h) {
 }
 
 // closestIntersect — K/kernel.h:14-24
+template <bool WIDE>
 DEV bool closest_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h, f3& point, LdsStack& stack) {
-    bool hit = octree_hit(S, o, d, draw_depth, h);
+    bool hit = octree_hit<WIDE>(S, o, d, draw_depth, h);
     if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, o, d, h, stack);
     if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, o, d, h, stack);
     if (hit) point = o + d * (h.distance - kOffset);
@@ -88,7 +116,7 @@ DEV void put_record(HitRecord* out, int& n, bool hit, const Hit& h, f3 point) {
 }
 
 // One sample — K/rayTracer.cl:55-107
-template <bool RECORD>
+template <bool RECORD, bool WIDE>
 DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O, int seed, int gid, LdsStack& stack,
                    HitRecord* rec_out, int* rec_n) {
     unsigned rng = (unsigned)seed + (unsigned)gid;
@@ -105,7 +133,7 @@ DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O,
     f3 point = mk3(0, 0, 0);
     int depth = 0, nrec = 0;
     for (;;) {
-        bool hit = closest_hit(S, o, d, O.draw_depth, h, point, stack);
+        bool hit = closest_hit<WIDE>(S, o, d, O.draw_depth, h, point, stack);
         if (RECORD) put_record(rec_out, nrec, hit, h, point);
         if (!hit) {
             radiance = radiance + sky_radiance(S, d, throughput, 1.0f);  // record.emittance = 1
@@ -124,7 +152,7 @@ DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O,
             h.emittance = rt_fabs(dot(d, h.normal));  // written to the main record, then copied (K/sky.h:90)
             Hit sh = h;
             f3 sp = h.normal;  // the copy's dead point = normal (K/wavefront.h:73)
-            bool shadowed = closest_hit(S, o, d, O.draw_depth, sh, sp, stack);
+            bool shadowed = closest_hit<WIDE>(S, o, d, O.draw_depth, sh, sp, stack);
             if (RECORD) put_record(rec_out, nrec, shadowed, sh, sp);
             if (!shadowed) radiance = radiance + sky_radiance(S, d, throughput, sh.emittance);
         }
@@ -147,6 +175,7 @@ DEV int shard_gid(const ShardView& T, int local) {
     return (t * T.world + T.rank) * T.tile + w;
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, RenderOpts O, ShardView T, PassSeeds P,
                                                      float* __restrict__ res) {
     extern __shared__ int lds[];
@@ -158,7 +187,7 @@ __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, R
     float* px = res + 3 * (size_t)gid;
     f3 mean = mk3(px[0], px[1], px[2]);
     for (int k = 0; k < P.n; k++) {
-        f3 c = sample_path<false>(S, C, O, P.seed[k], gid, stack, nullptr, nullptr);
+        f3 c = sample_path<false, WIDE>(S, C, O, P.seed[k], gid, stack, nullptr, nullptr);
         int spp = P.first_spp + k;
         float fs = (float)spp, fs1 = (float)(spp + 1);
         mean = f3{(mean.x * fs + c.x) / fs1, (mean.y * fs + c.y) / fs1, (mean.z * fs + c.z) / fs1};
@@ -168,6 +197,7 @@ __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, R
     px[2] = mean.z;
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraView C, RenderOpts O, int seed,
                                                              const int* __restrict__ gids, int n,
                                                              HitRecord* __restrict__ out, int* __restrict__ counts,
@@ -178,7 +208,7 @@ __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraV
     if (i >= n) return;
     HitRecord local[kMaxTraces];
     int cnt = 0;
-    f3 c = sample_path<true>(S, C, O, seed, gids[i], stack, local, &cnt);
+    f3 c = sample_path<true, WIDE>(S, C, O, seed, gids[i], stack, local, &cnt);
     for (int k = 0; k < cnt; k++) out[(size_t)i * kMaxTraces + k] = local[k];
     counts[i] = cnt;
     radiance[3 * i] = c.x;
@@ -187,6 +217,7 @@ __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraV
 }
 
 // preview — K/rayTracer.cl:115-217
+template <bool WIDE>
 __global__ void __launch_bounds__(256) preview_lanes(SceneView S, CameraView C, RenderOpts O, int* __restrict__ argb) {
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
@@ -210,7 +241,7 @@ __global__ void __launch_bounds__(256) preview_lanes(SceneView S, CameraView C, 
     h.emittance = 0;
     f3 point;
     f4 c;
-    if (closest_hit(S, o, d, O.draw_depth, h, point, stack)) {
+    if (closest_hit<WIDE>(S, o, d, O.draw_depth, h, point, stack)) {
         float shading = dot(h.normal, mk3(0.25f, 0.866f, 0.433f));
         shading = rt_fmax(0.3f, shading);
         c = f4{h.color.x * shading, h.color.y * shading, h.color.z * shading, 0};
@@ -253,6 +284,9 @@ __global__ void math_selftest_kernel(int which, int n, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------ launchers
+// variant bit 0 set = force the reference-layout octree walk (K/octree.h:81-89 as written)
+static bool use_wide(int variant, const SceneView& S) { return S.wide != nullptr && !(variant & 1); }
+
 static size_t stack_lds_bytes(const SceneView& S, int block) {
     bool need = !S.world_bvh_empty || !S.actor_bvh_empty;
     return need ? (size_t)kBvhStackEntries * block * sizeof(int) : 0;
@@ -260,29 +294,39 @@ static size_t stack_lds_bytes(const SceneView& S, int block) {
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, hipStream_t stream) {
-    (void)variant;
     const int block = 256;
     int grid = (T.n_local + block - 1) / block;
     if (grid <= 0 || P.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_lanes, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
+    if (use_wide(variant, S))
+        hipLaunchKernelGGL(render_lanes<true>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
+    else
+        hipLaunchKernelGGL(render_lanes<false>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
     return hipGetLastError();
 }
 
-hipError_t launch_trace_records(const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
+hipError_t launch_trace_records(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
                                 const int* gids_dev, int n, HitRecord* out, int* counts, float* radiance,
                                 hipStream_t stream) {
     const int block = 256;
     int grid = (n + block - 1) / block;
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL(trace_records_kernel, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, seed,
-                       gids_dev, n, out, counts, radiance);
+    if (use_wide(variant, S))
+        hipLaunchKernelGGL(trace_records_kernel<true>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O,
+                           seed, gids_dev, n, out, counts, radiance);
+    else
+        hipLaunchKernelGGL(trace_records_kernel<false>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O,
+                           seed, gids_dev, n, out, counts, radiance);
     return hipGetLastError();
 }
 
-hipError_t launch_preview(const SceneView& S, const CameraView& C, const RenderOpts& O, int* argb, hipStream_t stream) {
+hipError_t launch_preview(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int* argb,
+                          hipStream_t stream) {
     const int block = 256;
     int grid = (C.width * C.height + block - 1) / block;
-    hipLaunchKernelGGL(preview_lanes, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, argb);
+    if (use_wide(variant, S))
+        hipLaunchKernelGGL(preview_lanes<true>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, argb);
+    else
+        hipLaunchKernelGGL(preview_lanes<false>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, argb);
     return hipGetLastError();
 }
 

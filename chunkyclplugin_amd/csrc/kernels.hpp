@@ -40,10 +40,11 @@ struct PassSeeds {
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, hipStream_t stream);
-hipError_t launch_trace_records(const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
+hipError_t launch_trace_records(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
                                 const int* gids_dev, int n, HitRecord* out, int* counts, float* radiance,
                                 hipStream_t stream);
-hipError_t launch_preview(const SceneView& S, const CameraView& C, const RenderOpts& O, int* argb, hipStream_t stream);
+hipError_t launch_preview(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int* argb,
+                          hipStream_t stream);
 hipError_t launch_math_selftest(int which, int n, const float* a, const float* b, float* out, hipStream_t stream);
 
 }  // namespace chunky

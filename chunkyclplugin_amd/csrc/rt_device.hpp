@@ -65,6 +65,10 @@ struct SceneView {
     f3 su, sv, sw;
     float sun_radius_cos;             // cos(0.03f), K/sky.h:73
     int world_bvh_empty, actor_bvh_empty;  // K/bvh.h:23-32 sentinel, tested at upload
+    // wide re-layout of the octree (widetree.hpp); null when it could not be built
+    const uint32_t* __restrict__ wide;
+    int wide_nlev;
+    int wide_shift[6], wide_bits[6];
 };
 
 struct CameraView {

@@ -1,0 +1,90 @@
+// widetree.cpp — see widetree.hpp
+#include "widetree.hpp"
+
+#include <deque>
+
+namespace chunky {
+
+int default_wide_levels(int depth, int* level_bits) {
+    if (depth <= 0) {
+        level_bits[0] = 0;
+        return 1;
+    }
+    int nlev = (depth + 2) / 3;
+    if (nlev > kWideMaxLevels) nlev = kWideMaxLevels;
+    int rest = depth - 3 * (nlev - 1);
+    level_bits[0] = rest;
+    for (int i = 1; i < nlev; i++) level_bits[i] = 3;
+    return nlev;
+}
+
+namespace {
+struct Job {
+    int64_t base;  // offset of the node to fill
+    int level;     // level index
+    int32_t root;  // octree value covering the node's region
+};
+}  // namespace
+
+bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_bits, int nlev, WideTree* out,
+                     const char** why) {
+    static const char* kDepth = "octree depth outside 0..15";
+    static const char* kBits = "level bits do not add up to the octree depth";
+    static const char* kPtr = "block pointer does not fit 27 bits";
+    static const char* kTree = "octree node outside the array";
+    static const char* kSize = "wide tree would exceed 2^31 entries";
+    if (depth < 0 || depth > 15) return *why = kDepth, false;
+    int sum = 0;
+    for (int i = 0; i < nlev; i++) sum += level_bits[i];
+    if (nlev < 1 || nlev > kWideMaxLevels || sum != depth) return *why = kBits, false;
+    out->nlev = nlev;
+    int s = depth;
+    for (int i = 0; i < nlev; i++) {
+        s -= level_bits[i];
+        out->bits[i] = level_bits[i];
+        out->shift[i] = s;
+    }
+    std::vector<uint32_t>& d = out->data;
+    d.clear();
+    d.resize((size_t)1 << (3 * level_bits[0]));
+    std::deque<Job> queue;
+    queue.push_back(Job{0, 0, oct[0]});
+    while (!queue.empty()) {  // breadth-first: nodes of one level are contiguous, upper levels first
+        Job j = queue.front();
+        queue.pop_front();
+        const int b = out->bits[j.level], sh = out->shift[j.level];
+        const int side = 1 << b;
+        for (int ex = 0; ex < side; ex++)
+            for (int ey = 0; ey < side; ey++)
+                for (int ez = 0; ez < side; ez++) {
+                    int32_t val = j.root;
+                    int lvl = sh + b;
+                    for (int k = b - 1; k >= 0 && val > 0; k--) {
+                        lvl--;
+                        int64_t at = (int64_t)val + ((((ex >> k) & 1) << 2) | (((ey >> k) & 1) << 1) | ((ez >> k) & 1));
+                        if (at < 0 || at >= n) return *why = kTree, false;
+                        val = oct[at];
+                    }
+                    const int64_t slot = j.base + (((int64_t)ex << (2 * b)) | ((int64_t)ey << b) | ez);
+                    if (val <= 0) {
+                        uint32_t code = (uint32_t)(-(int64_t)val);
+                        if (code == 0x7FFFFFFEu)
+                            code = kWideAny;
+                        else if (code >= kWideAny)
+                            return *why = kPtr, false;
+                        d[(size_t)slot] = kWideLeaf | ((uint32_t)lvl << 27) | code;
+                    } else {
+                        if (j.level + 1 >= nlev) return *why = kTree, false;  // a branch below level 0
+                        const int64_t child = (int64_t)d.size();
+                        const int64_t csize = (int64_t)1 << (3 * out->bits[j.level + 1]);
+                        if (child + csize >= ((int64_t)1 << 31)) return *why = kSize, false;
+                        d.resize((size_t)(child + csize));
+                        d[(size_t)slot] = (uint32_t)child;
+                        queue.push_back(Job{child, j.level + 1, val});
+                    }
+                }
+    }
+    return true;
+}
+
+}  // namespace chunky

@@ -1,0 +1,41 @@
+// widetree.hpp — re-layout of the packed octree into a shallow, wide tree (host side, at upload).
+//
+// The reference looks a block up by descending the octree one bit per level from the root on every
+// march step (K/octree.h:81-89: up to `depth` dependent 4-byte loads).  The lookup is a pure
+// function cell -> (leaf value, leaf level), so any structure that returns the same pair for every
+// cell is parity-safe.  The wide tree consumes `bits[i]` address bits per
+// axis at level i, i.e. a node at level i is a dense (2^bits[i])^3 grid of 32-bit entries:
+//
+//   entry >= 0 : int offset of the child node (level i+1) inside the array
+//   entry <  0 : leaf — bits 30..27 = level of the octree leaf that contains the cell (its cube has
+//                edge 2^level; needed for the leaf-exit box of K/octree.h:103-106),
+//                bits 26..0 = block-palette pointer (K/octree.h:88), 0x7FFFFFF = ANY_TYPE (K/block.h:32)
+//
+// With bits = {3,3,3} a depth-9 world needs at most 3 dependent loads per lookup instead of 9.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace chunky {
+
+constexpr int kWideMaxLevels = 6;
+constexpr uint32_t kWideLeaf = 0x80000000u;
+constexpr uint32_t kWideAny = 0x7FFFFFFu;
+
+struct WideTree {
+    std::vector<uint32_t> data;
+    int nlev = 0;
+    int shift[kWideMaxLevels] = {0};
+    int bits[kWideMaxLevels] = {0};
+};
+
+// Returns false (with *why set) when the octree cannot be expressed: depth > 15, a block pointer
+// that does not fit 27 bits, or a malformed tree.
+bool build_wide_tree(const int32_t* oct, int64_t n_ints, int depth, const int* level_bits, int nlev, WideTree* out,
+                     const char** why);
+
+// Default split of `depth` address bits into levels: 3 bits per level from the bottom, the
+// remainder (1..3 bits) at the top.
+int default_wide_levels(int depth, int* level_bits);
+
+}  // namespace chunky

@@ -18,7 +18,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libchunky_hip.so")
 HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "chunky_hip.h")
-SOURCES = ["kernels.hip", "capi.hip"]
+SOURCES = ["kernels.hip", "capi.hip", "widetree.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 MAX_TRACES = 10
@@ -110,6 +110,7 @@ def lib() -> C.CDLL:
             "chunky_render_run": [vp, vp, C.POINTER(i32), i32, i32, POST_RENDER_FN, vp],
             "chunky_java_random_ints": [i64, vp, C.c_int],
             "chunky_selftest_math": [vp, C.c_int, C.c_int, vp, vp, vp],
+            "chunky_widetree_lookup": [vp, i64, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.POINTER(i64)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -132,3 +133,17 @@ def java_random_ints(n: int, seed: int = 0) -> np.ndarray:
     out = np.zeros(n, np.int32)
     check(lib().chunky_java_random_ints(seed, ptr(out), n))
     return out
+
+
+def widetree_lookup(tree: np.ndarray, depth: int, xyz: np.ndarray, level_bits=None):
+    """Host-side check of the upload-time octree re-layout: (data, level, n_entries) for each cell."""
+    tree = np.ascontiguousarray(tree, np.int32)
+    xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+    data = np.zeros(len(xyz), np.int32)
+    level = np.zeros(len(xyz), np.int32)
+    n_entries = C.c_int64()
+    lb = None if level_bits is None else np.ascontiguousarray(level_bits, np.int32)
+    check(lib().chunky_widetree_lookup(ptr(tree), tree.size, depth, None if lb is None else ptr(lb),
+                                       0 if lb is None else lb.size, ptr(xyz), len(xyz), ptr(data), ptr(level),
+                                       C.byref(n_entries)))
+    return data, level, n_entries.value

@@ -155,6 +155,13 @@ int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_sp
 /* The seed stream itself: first n values of new java.util.Random(seed).nextInt(). */
 int chunky_java_random_ints(int64_t seed, int32_t* out, int n);
 
+/* ---- host-side verification hook for the octree re-layout done at upload (no device needed):
+ * builds the wide tree of chunkyclplugin_amd/csrc/widetree.hpp from `tree` and looks n cells up in
+ * it, returning for each the block pointer (K/octree.h:88) and the leaf level.  level_bits == NULL
+ * uses the default split.  *n_entries receives the size of the re-laid-out array. */
+int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int depth, const int32_t* level_bits, int n_levels,
+                           const int32_t* xyz /* 3n */, int n, int32_t* data_out, int32_t* level_out, int64_t* n_entries);
+
 /* ---- self test: evaluate the rt_math.h contract on the device (bit-compared with the host by tests) */
 int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const float* a, const float* b, float* out);
 

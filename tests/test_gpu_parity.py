@@ -34,11 +34,17 @@ def assert_radiance(got, want, what):
     pytest.fail(f"{what}: within {REL_TOL} but not bit-exact ({bad} values differ) — the arithmetic contract is broken")
 
 
-def make_renderer(gpu_instance, sc):
+# CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (wide-tree lookup),
+# 1 = the reference-layout octree walk of K/octree.h:81-89
+VARIANTS = [0, 1]
+
+
+def make_renderer(gpu_instance, sc, variant=0):
     loader = HipSceneLoader(gpu_instance)
     loader.load_packed(sc)
     r = HipPathTracingRenderer(loader, sc.width, sc.height)
     r.set_camera(sc.projector_type, sc.camera)
+    r.set_option(native.OPT_KERNEL, variant)
     return loader, r
 
 
@@ -103,12 +109,13 @@ def _fma3(x, y):
 
 
 # ---- golden images: outputs of the reference kernel itself -------------------------------------
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name", gs.NAMES)
-def test_render_matches_reference_goldens(gpu_instance, name):
+def test_render_matches_reference_goldens(gpu_instance, name, variant):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     sc = gs.make(name)
     assert gs.input_digest(sc) == str(g["digest"])
-    loader, r = make_renderer(gpu_instance, sc)
+    loader, r = make_renderer(gpu_instance, sc, variant)
     r.render_passes(g["seeds"])
     assert_radiance(r.read(), g["res"], f"{name} res")
     np.testing.assert_array_equal(r.preview(), g["preview"])          # integer image: exact
@@ -129,13 +136,14 @@ def test_render_matches_reference_goldens(gpu_instance, name):
 
 
 # ---- seeded inputs vs the CPU oracle -----------------------------------------------------------
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name,w,h,passes,first", [("outdoor", 160, 96, 6, 0), ("entities", 128, 80, 3, 4),
                                                     ("indoor_sun", 128, 80, 5, 0), ("inside", 96, 64, 4, 1)])
-def test_render_matches_oracle(gpu_instance, port, name, w, h, passes, first):
+def test_render_matches_oracle(gpu_instance, port, name, w, h, passes, first, variant):
     sc = gs.make(name).with_view(w, h)
     seeds = scenes.java_random_ints(passes + 2)[2:]
     want = port.render_passes(sc, seeds, first_spp=first)
-    loader, r = make_renderer(gpu_instance, sc)
+    loader, r = make_renderer(gpu_instance, sc, variant)
     r.render_passes(seeds, first_buffer_spp=first)
     assert_radiance(r.read(), want, name)
     np.testing.assert_array_equal(r.preview(), port.preview(sc))

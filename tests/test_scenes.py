@@ -75,3 +75,28 @@ def test_sun_and_camera_packing():
     M = cam[3:12].reshape(3, 3)
     assert np.allclose(M @ M.T, np.eye(3), atol=1e-6)
     assert np.allclose(M[:, 2], np.array([3, 0, 4]) / 5, atol=1e-6)   # third column = forward
+
+
+def test_wide_tree_relayout_preserves_every_lookup():
+    """The upload-time re-layout (widetree.hpp) must return the reference's (leaf value, leaf level)
+    for every cell — K/octree.h:81-89 is a pure function of the cell."""
+    import pytest
+    from chunkyclplugin_amd import native
+    rng = np.random.default_rng(5)
+    sc = scenes.outdoor_world(chunks=2, height=48, seed=101)          # depth 6, with ANY_TYPE interior
+    S = 1 << sc.octree_depth
+    xyz = rng.integers(0, S, size=(4000, 3)).astype(np.int32)
+    want = np.array([lookup(sc.octree, sc.octree_depth, *map(int, c)) for c in xyz])
+    for bits in (None, [3, 3], [2, 2, 2], [1, 1, 1, 1, 1, 1], [6], [4, 2], [1, 2, 3]):
+        data, level, n = native.widetree_lookup(sc.octree, sc.octree_depth, xyz, bits)
+        np.testing.assert_array_equal(data, want[:, 0], err_msg=str(bits))
+        np.testing.assert_array_equal(level, want[:, 1], err_msg=str(bits))
+        assert n >= 8
+    assert (want[:, 0] == scenes.ANY_TYPE).any() and (want[:, 1] > 1).any()
+    # single-leaf world, and rejects what it cannot express
+    d, l, n = native.widetree_lookup(np.array([-6], np.int32), 4, [[1, 2, 3]])
+    assert (d[0], l[0]) == (6, 4)
+    with pytest.raises(native.ChunkyHipError):
+        native.widetree_lookup(sc.octree, sc.octree_depth, xyz, [3, 2])     # bits do not sum to depth
+    with pytest.raises(native.ChunkyHipError):
+        native.widetree_lookup(np.array([-(1 << 28)], np.int32), 3, [[0, 0, 0]])  # pointer too large

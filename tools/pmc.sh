@@ -1,0 +1,23 @@
+#!/bin/bash
+# tools/pmc.sh <tag> [bench args...] — PMC counter passes for the render kernel, one rocprofv3 run per group
+# (SQ has 8 slots, TCC 4; FETCH_SIZE costs 3, WRITE_SIZE 2 — MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# Run on the GPU box through gpurun; results land in gpurun_out/pmc_<tag>/<group>/ and a summary in
+# gpurun_out/pmc_<tag>/summary.json (tools/pmc_summary.py).
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+declare -A G
+G[sq1]="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+G[sq2]="SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_BRANCH"
+G[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"
+G[tcp]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum"
+G[fetch]="FETCH_SIZE"
+G[write]="WRITE_SIZE"
+for g in ${PMC_GROUPS:-sq1 sq2 tcc tcp fetch write}; do
+  timeout 600 rocprofv3 --pmc ${G[$g]} --output-format csv -d $OUT/$g -- python3 $R/bench.py --no-cpu --steps 2 --warmup 1 "$@" > $OUT/$g.log 2>&1 || echo "group $g failed"
+done
+python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.json
+cat $OUT/summary.json
