@@ -96,7 +96,7 @@ struct chunky_render {
     RenderOpts opts{256, 5, 13.0f};
     int kernel_variant = 0;
     ShardView shard{0, 1, 256, 0};
-    DevBuf own_fb;
+    DevBuf own_fb, work_counter;
     float* fb = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // timing brackets of enqueued launches
     std::vector<hipEvent_t> free_events;
@@ -411,6 +411,8 @@ extern "C" int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int wi
     r->own_fb.bytes = bytes;
     r->fb = (float*)r->own_fb.p;
     HIP_TRY(hipMemsetAsync(r->fb, 0, bytes, ctx->stream));
+    HIP_TRY(hipMalloc(&r->work_counter.p, 64));
+    r->work_counter.bytes = 64;
     r->shard = ShardView{0, 1, 256, width * height};
     scene->refs++;
     *out = r.release();
@@ -542,7 +544,7 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
         HIP_TRY(get_event(r, &e0));
         HIP_TRY(get_event(r, &e1));
         HIP_TRY(hipEventRecord(e0, r->ctx->stream));
-        HIP_TRY(launch_render(r->kernel_variant, S, r->cam, r->opts, r->shard, ps, r->fb, r->ctx->stream));
+        HIP_TRY(launch_render(r->kernel_variant, S, r->cam, r->opts, r->shard, ps, r->fb, (int*)r->work_counter.p, r->ctx->stream));
         HIP_TRY(hipEventRecord(e1, r->ctx->stream));
         r->pending.emplace_back(e0, e1);
         done += ps.n;

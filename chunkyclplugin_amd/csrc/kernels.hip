@@ -197,6 +197,249 @@ __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, R
     px[2] = mean.z;
 }
 
+// ---------------------------------------------------------------------------------------------
+// render_waves — the wave-scheduled form of the same path.
+//
+// Each lane is a persistent path-state machine; a lane claims a pixel from a global counter, runs
+// all passes of the launch for it (running mean in registers) and claims the next one.  A lane is
+// always in one of three states, and every iteration the WAVE votes (ballot + popcount, all
+// scalar) for the state most lanes are waiting in and executes only that phase:
+//
+//   MARCH  one octree march step: limit checks, cell, leaf lookup; air -> leaf-exit, stay;
+//          block candidate -> BLOCK; end of trace -> SHADE
+//   BLOCK  block-model intersection + material/texture test at the current cell; hit -> SHADE,
+//          rejected -> leaf-exit, back to MARCH
+//   SHADE  everything between two traces: entity BVHs, sky / sun lookup, throughput update, sun
+//          sampling, cosine bounce, accumulation, next pass / next pixel, primary ray, trace setup
+//
+// Per-path arithmetic is exactly sample_path's (the same helpers in the same order on the same
+// values), so the image is bit-identical; only which lanes execute together changes.  On the
+// benchmark view the one-lane-per-path form keeps 19 % of the VALU lanes busy (profiles/), because
+// a wave waits for its longest march and its deepest path.
+enum : int { ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2, ST_DONE = 3 };
+
+struct LaneState {
+    // pixel / pass
+    int gid, pass;
+    f3 mean;
+    unsigned rng;
+    // path
+    f3 radiance, throughput, o, d;
+    int depth;
+    bool shadow;       // the current trace is the sun-sample trace of K/rayTracer.cl:101-106
+    float shadow_emit; // sampleRecord.emittance = |dot(sun dir, normal)|
+    // trace
+    f3 inv;
+    float dist_march;
+    int steps;
+    bool oct_hit;
+    int cand_data, cand_level;
+    // main record
+    Hit h;
+    f3 point;
+};
+
+template <bool WIDE>
+DEV void leaf_exit(const SceneView& S, LaneState& L, f3 po, int bx, int by, int bz, int level) {
+    int lx = bx >> level, ly = by >> level, lz = bz >> level;
+    L.dist_march += box_exit((float)(lx << level), (float)((lx + 1) << level), (float)(ly << level),
+                             (float)((ly + 1) << level), (float)(lz << level), (float)((lz + 1) << level), po, L.inv) +
+                    kOffset;
+    L.steps += 1;
+}
+
+// Start of Octree_octreeIntersect (K/octree.h:44-64): returns the next state.
+DEV int trace_setup(const SceneView& S, LaneState& L) {
+    const int depth = S.octree_depth;
+    L.inv = rcp3(L.d);
+    L.dist_march = 0;
+    L.steps = 0;
+    L.oct_hit = false;
+    int lx = (int)rt_floor(L.o.x) >> depth, ly = (int)rt_floor(L.o.y) >> depth, lz = (int)rt_floor(L.o.z) >> depth;
+    if ((lx != 0) | (ly != 0) | (lz != 0)) {
+        float size = (float)(1 << depth);
+        float dist = box_quick(0, size, 0, size, 0, size, L.o, L.inv);
+        if (dist != dist || dist < 0) return ST_SHADE;
+        L.dist_march += dist + kOffset;
+    }
+    return ST_MARCH;
+}
+
+template <bool WIDE>
+DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
+    const int depth = S.octree_depth;
+    if (L.steps >= O.draw_depth || L.dist_march > L.h.distance) return ST_SHADE;
+    f3 pos = L.o + L.d * L.dist_march;
+    f3 po = pos + L.d * kOffset;
+    int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
+    if (((bx | by | bz) >> depth) != 0) return ST_SHADE;
+    int level, data;
+    leaf_lookup<WIDE>(S, bx, by, bz, data, level);
+    if (data != 0 && data != kAnyType) {
+        L.cand_data = data;
+        L.cand_level = level;
+        return ST_BLOCK;
+    }
+    leaf_exit<WIDE>(S, L, po, bx, by, bz, level);
+    return ST_MARCH;
+}
+
+template <bool WIDE>
+DEV int block_phase(const SceneView& S, LaneState& L) {
+    f3 pos = L.o + L.d * L.dist_march;
+    f3 po = pos + L.d * kOffset;
+    int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
+    Hit t = L.h;
+    float dist = block_hit(S, L.cand_data, bx, by, bz, pos, L.d, L.inv, t);
+    if (!L.shadow) {  // a rejected cube has already overwritten the normal (K/block.h:59-60)
+        L.h.normal = t.normal;
+        L.h.color = t.color;
+        L.h.emittance = t.emittance;
+    }
+    if (dist == dist) {
+        if (!L.shadow) {
+            L.h.distance = L.dist_march + dist;
+            L.h.material = L.cand_data;
+        }
+        L.oct_hit = true;
+        return ST_SHADE;
+    }
+    leaf_exit<WIDE>(S, L, po, bx, by, bz, L.cand_level);
+    return ST_MARCH;
+}
+
+struct WorkQueue {
+    int* next;  // next unclaimed local pixel slot
+};
+
+template <bool WIDE>
+DEV int shade_phase(const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
+                    const PassSeeds& P, WorkQueue Q, float* __restrict__ res, LaneState& L, LdsStack& stack,
+                    bool fresh) {
+    bool need_pixel = fresh;
+    if (!fresh) {
+        // ---- finish closestIntersect (K/kernel.h:14-24) ----
+        bool hit = L.oct_hit;
+        if (!L.shadow) {
+            if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, L.o, L.d, L.h, stack);
+            if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, L.o, L.d, L.h, stack);
+        } else if (!hit && (!S.world_bvh_empty || !S.actor_bvh_empty)) {
+            Hit sh = L.h;
+            if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, L.o, L.d, sh, stack);
+            if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, L.o, L.d, sh, stack);
+        }
+        bool bounce = false, path_done = false;
+        if (!L.shadow) {
+            if (!hit) {
+                L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, 1.0f);
+                path_done = true;
+            } else {
+                L.point = L.o + L.d * (L.h.distance - kOffset);
+                // applyRayColor (K/kernel.h:33-44)
+                L.o = L.point;
+                f3 c = mk3(L.h.color.x, L.h.color.y, L.h.color.z);
+                L.throughput = L.throughput * c;
+                L.radiance = L.radiance + (c * (L.h.emittance * O.emitter_scale)) * L.throughput;
+                if (S.sun_flags & 1) {
+                    L.d = sun_sample(S, L.rng);
+                    L.h.emittance = rt_fabs(dot(L.d, L.h.normal));
+                    L.shadow_emit = L.h.emittance;
+                    L.shadow = true;
+                    return trace_setup(S, L);
+                }
+                bounce = true;
+            }
+        } else {
+            if (!hit) L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, L.shadow_emit);
+            L.shadow = false;
+            bounce = true;
+        }
+        if (bounce) {
+            // nextPath (K/kernel.h:46-98)
+            L.o = L.point;
+            L.d = diffuse_bounce(L.h.normal, L.rng);
+            L.o = L.o + L.d * kOffset;
+            L.depth += 1;
+            L.h.distance = rt_inf();
+            if (L.depth < O.max_depth) return trace_setup(S, L);
+            path_done = true;
+        }
+        // ---- accumulate (K/rayTracer.cl:109-112) ----
+        int spp = P.first_spp + L.pass;
+        float fs = (float)spp, fs1 = (float)(spp + 1);
+        L.mean = f3{(L.mean.x * fs + L.radiance.x) / fs1, (L.mean.y * fs + L.radiance.y) / fs1,
+                    (L.mean.z * fs + L.radiance.z) / fs1};
+        L.pass += 1;
+        if (L.pass >= P.n) {
+            float* px = res + 3 * (size_t)L.gid;
+            px[0] = L.mean.x;
+            px[1] = L.mean.y;
+            px[2] = L.mean.z;
+            need_pixel = true;
+        }
+    }
+    if (need_pixel) {
+        int slot = atomicAdd(Q.next, 1);
+        int gid = slot < T.n_local ? shard_gid(T, slot) : C.width * C.height;
+        if (gid >= C.width * C.height) return ST_DONE;
+        L.gid = gid;
+        L.pass = 0;
+        const float* px = res + 3 * (size_t)gid;
+        L.mean = mk3(px[0], px[1], px[2]);
+    }
+    // ---- new sample (K/rayTracer.cl:55-91) ----
+    L.rng = (unsigned)P.seed[L.pass] + (unsigned)L.gid;
+    rt_pcg_next(&L.rng);
+    {
+        // locals, not struct members, as out-parameters: keeps LaneState promotable to registers
+        unsigned rng = L.rng;
+        f3 o, d;
+        primary_ray(C, L.gid, rng, false, o, d);
+        L.rng = rng;
+        L.o = o;
+        L.d = d;
+    }
+    L.radiance = mk3(0, 0, 0);
+    L.throughput = mk3(1, 1, 1);
+    L.depth = 0;
+    L.shadow = false;
+    L.h.distance = rt_inf();
+    return trace_setup(S, L);
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(256, 4) render_waves(SceneView S, CameraView C, RenderOpts O, ShardView T, PassSeeds P,
+                                                     WorkQueue Q, float* __restrict__ res) {
+    extern __shared__ int lds[];
+    LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
+    LaneState L;
+    L.h.material = 0;
+    L.h.normal = mk3(0, 0, 0);
+    L.h.color = f4{0, 0, 0, 0};
+    L.h.emittance = 0;
+    L.point = mk3(0, 0, 0);
+    L.shadow_emit = 0;
+    L.cand_data = 0;
+    L.cand_level = 0;
+    L.pass = 0;
+    L.gid = 0;
+    L.mean = mk3(0, 0, 0);
+    int st = shade_phase<WIDE>(S, C, O, T, P, Q, res, L, stack, true);
+    for (;;) {
+        const int n_march = __popcll(__ballot(st == ST_MARCH));
+        const int n_block = __popcll(__ballot(st == ST_BLOCK));
+        const int n_shade = __popcll(__ballot(st == ST_SHADE));
+        if ((n_march | n_block | n_shade) == 0) break;
+        if (n_march >= n_block && n_march >= n_shade) {
+            if (st == ST_MARCH) st = march_phase<WIDE>(S, O, L);
+        } else if (n_block >= n_shade) {
+            if (st == ST_BLOCK) st = block_phase<WIDE>(S, L);
+        } else {
+            if (st == ST_SHADE) st = shade_phase<WIDE>(S, C, O, T, P, Q, res, L, stack, false);
+        }
+    }
+}
+
 template <bool WIDE>
 __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraView C, RenderOpts O, int seed,
                                                              const int* __restrict__ gids, int n,
@@ -284,7 +527,8 @@ __global__ void math_selftest_kernel(int which, int n, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------ launchers
-// variant bit 0 set = force the reference-layout octree walk (K/octree.h:81-89 as written)
+// variant bit 0 set = force the reference-layout octree walk (K/octree.h:81-89 as written);
+// variant bit 1 set = one lane per path for the whole launch (render_lanes) instead of render_waves
 static bool use_wide(int variant, const SceneView& S) { return S.wide != nullptr && !(variant & 1); }
 
 static size_t stack_lds_bytes(const SceneView& S, int block) {
@@ -293,7 +537,39 @@ static size_t stack_lds_bytes(const SceneView& S, int block) {
 }
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
-                         const PassSeeds& P, float* res, hipStream_t stream) {
+                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream) {
+    if (!(variant & 2) && work_counter) {
+        // wave-scheduled persistent kernel: one resident grid, lanes pull pixels from a counter
+        const int block = 256;
+        static int blocks_per_cu[2] = {0, 0};
+        static int n_cu = 0;
+        const bool wide = use_wide(variant, S);
+        const size_t lds = stack_lds_bytes(S, block);
+        if (n_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+            n_cu = prop.multiProcessorCount;
+        }
+        int& bpc = blocks_per_cu[wide ? 1 : 0];
+        int occ = 0;
+        hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_waves<true>, block, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_waves<false>, block, lds);
+        if (e != hipSuccess) return e;
+        bpc = occ > 0 ? occ : 1;
+        int want = (T.n_local + block - 1) / block;
+        int grid = n_cu * bpc;
+        if (grid > want) grid = want;
+        if (grid <= 0 || P.n <= 0) return hipSuccess;
+        e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
+        if (e != hipSuccess) return e;
+        WorkQueue Q{work_counter};
+        if (wide)
+            hipLaunchKernelGGL(render_waves<true>, dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res);
+        else
+            hipLaunchKernelGGL(render_waves<false>, dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res);
+        return hipGetLastError();
+    }
     const int block = 256;
     int grid = (T.n_local + block - 1) / block;
     if (grid <= 0 || P.n <= 0) return hipSuccess;

@@ -39,7 +39,7 @@ struct PassSeeds {
 };
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
-                         const PassSeeds& P, float* res, hipStream_t stream);
+                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream);
 hipError_t launch_trace_records(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
                                 const int* gids_dev, int n, HitRecord* out, int* counts, float* radiance,
                                 hipStream_t stream);

@@ -35,8 +35,8 @@ def assert_radiance(got, want, what):
 
 
 # CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (wide-tree lookup),
-# 1 = the reference-layout octree walk of K/octree.h:81-89
-VARIANTS = [0, 1]
+# bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes)
+VARIANTS = [0, 1, 2, 3]
 
 
 def make_renderer(gpu_instance, sc, variant=0):
