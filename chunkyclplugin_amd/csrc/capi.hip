@@ -74,7 +74,8 @@ struct DevBuf {
 
 struct chunky_scene {
     chunky_ctx* ctx = nullptr;
-    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide;
+    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info;
+    std::vector<int32_t> host_blocks, host_materials;  // kept to rebuild block_info when either changes
     WideTree wide_meta;  // data vector released after upload; nlev == 0 when absent
     int octree_depth = -1;
     int atlas_w = 0, atlas_h = 0, atlas_layers = 0;
@@ -248,6 +249,25 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
         default: return fail(CHUNKY_E_INVALID, "set_palette: unknown kind %d", kind);
     }
     HIP_TRY(dst->upload(data, (size_t)n * 4, scene->ctx->stream));
+    if (kind == CHUNKY_PALETTE_BLOCK || kind == CHUNKY_PALETTE_MATERIAL) {
+        (kind == CHUNKY_PALETTE_BLOCK ? scene->host_blocks : scene->host_materials).assign(data, data + n);
+        // block_info: per block {type, pointer, 5 material words of a full cube, 0} (rt_device.hpp)
+        const std::vector<int32_t>&B = scene->host_blocks, &M = scene->host_materials;
+        scene->block_info.release();
+        if (!B.empty() && !M.empty()) {
+            std::vector<int32_t> info((B.size() / 2) * 8, 0);
+            for (size_t k = 0; k + 1 < B.size(); k += 2) {
+                int32_t* e = &info[(k / 2) * 8];
+                e[0] = B[k];
+                e[1] = B[k + 1];
+                if (B[k] == 1 && B[k + 1] >= 0 && (size_t)B[k + 1] + 5 <= M.size())
+                    for (int w = 0; w < 5; w++) e[2 + w] = M[(size_t)B[k + 1] + w];
+                else if (B[k] == 1)
+                    e[0] = 0x7FFFFFFF;  // malformed cube: an unknown model type never hits (K/block.h:44-47)
+            }
+            HIP_TRY(scene->block_info.upload(info.data(), info.size() * 4, scene->ctx->stream));
+        }
+    }
     return CHUNKY_OK;
 }
 
@@ -379,6 +399,7 @@ static int scene_view(const chunky_scene* s, SceneView* v) {
     v->sun_radius_cos = rt_cos(0.03f);
     v->world_bvh_empty = (s->world_empty || !s->world_bvh.p) ? 1 : 0;
     v->actor_bvh_empty = (s->actor_empty || !s->actor_bvh.p) ? 1 : 0;
+    v->block_info = (const int4*)s->block_info.p;
     v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;
     v->wide_nlev = s->wide_meta.nlev;
     for (int i = 0; i < 6; i++) {
@@ -411,8 +432,9 @@ extern "C" int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int wi
     r->own_fb.bytes = bytes;
     r->fb = (float*)r->own_fb.p;
     HIP_TRY(hipMemsetAsync(r->fb, 0, bytes, ctx->stream));
-    HIP_TRY(hipMalloc(&r->work_counter.p, 64));
-    r->work_counter.bytes = 64;
+    HIP_TRY(hipMalloc(&r->work_counter.p, 256));
+    r->work_counter.bytes = 256;
+    HIP_TRY(hipMemsetAsync(r->work_counter.p, 0, 256, ctx->stream));
     r->shard = ShardView{0, 1, 256, width * height};
     scene->refs++;
     *out = r.release();
@@ -574,6 +596,15 @@ extern "C" int chunky_render_kernel_time(chunky_render* r, float* total_ms, int*
     if (launches) *launches = r->timed_launches;
     r->timed_ms = 0;
     r->timed_launches = 0;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_phase_stats(chunky_render* r, uint64_t* out9, int reset) {
+    LOCK_RENDER(r);
+    if (!out9) return fail(CHUNKY_E_INVALID, "phase_stats: NULL output");
+    HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+    HIP_TRY(hipMemcpy(out9, (char*)r->work_counter.p + 8, 72, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset((char*)r->work_counter.p + 8, 0, 72));
     return CHUNKY_OK;
 }
 

@@ -44,7 +44,7 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
                 const int sh = S.wide_shift[i], b = S.wide_bits[i];
                 const unsigned ix = __builtin_amdgcn_ubfe((unsigned)bx, sh, b), iy = __builtin_amdgcn_ubfe((unsigned)by, sh, b),
                                iz = __builtin_amdgcn_ubfe((unsigned)bz, sh, b);
-                e = (int)tree[e + (int)((((ix << b) | iy) << b) | iz)];
+                e = (int)tree[(unsigned)e + ((((ix << b) | iy) << b) | iz)];  // unsigned: 32-bit offset off an SGPR base
             }
         }
         level = (e >> 27) & 15;
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, R
 // values), so the image is bit-identical; only which lanes execute together changes.  On the
 // benchmark view the one-lane-per-path form keeps 19 % of the VALU lanes busy (profiles/), because
 // a wave waits for its longest march and its deepest path.
-enum : int { ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2, ST_DONE = 3 };
+enum : int { ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2, ST_DONE = 3, ST_NEXT = 4, ST_SETUP = 5 };
 
 struct LaneState {
     // pixel / pass
@@ -312,58 +312,95 @@ struct WorkQueue {
     int* next;  // next unclaimed local pixel slot
 };
 
+// Pixel slots a wave has claimed but not handed to a lane yet: [next, end), wave-uniform.  One
+// returning atomic per kPixelBatch pixels per wave instead of one per shade round (a contended
+// device-scope atomic costs ~1-3 us, MI355X_MICROARCH.md "dequeue").
+constexpr int kPixelBatch = 32;
+struct PixelPool {
+    int next, end;
+};
+
+DEV int claim_slot(WorkQueue Q, PixelPool& pool, bool need) {
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0) return 0;
+    const int n_need = __popcll(mask);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    const int rem = pool.end - pool.next;
+    int slot = pool.next + rank;
+    if (rem >= n_need) {
+        pool.next += n_need;
+    } else {
+        // take what is left, then a fresh batch (large enough for every waiting lane)
+        const int want = n_need - rem > kPixelBatch ? n_need - rem : kPixelBatch;
+        int base = 0;
+        if (need && rank == 0) base = atomicAdd(Q.next, want);
+        base = __builtin_amdgcn_readfirstlane(__shfl(base, __ffsll((long long)mask) - 1));
+        if (rank >= rem) slot = base + (rank - rem);
+        pool.next = base + (n_need - rem);
+        pool.end = base + want;
+    }
+    return slot;
+}
+
+// SHADE, part 1: everything from the end of a trace to the start of the next one on the same path.
+// Returns ST_SETUP (a ray is ready to be traced) or ST_NEXT (the path is finished).
 template <bool WIDE>
-DEV int shade_phase(const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
-                    const PassSeeds& P, WorkQueue Q, float* __restrict__ res, LaneState& L, LdsStack& stack,
-                    bool fresh) {
+DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsStack& stack) {
+    // ---- finish closestIntersect (K/kernel.h:14-24) ----
+    bool hit = L.oct_hit;
+    if (!L.shadow) {
+        if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, L.o, L.d, L.h, stack);
+        if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, L.o, L.d, L.h, stack);
+    } else if (!hit && (!S.world_bvh_empty || !S.actor_bvh_empty)) {
+        Hit sh = L.h;
+        if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, L.o, L.d, sh, stack);
+        if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, L.o, L.d, sh, stack);
+    }
+    // Each block below appears once, so a shade round issues it once however the lanes split.
+    const bool main_trace = !L.shadow;
+    if (!hit) {  // intersectSky (K/kernel.h:26-31); record.emittance = 1 for the main ray (K/rayTracer.cl:95)
+        const float e = main_trace ? 1.0f : L.shadow_emit;
+        L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, e);
+        if (main_trace) return ST_NEXT;
+    }
+    bool bounce = true;
+    if (main_trace) {
+        L.point = L.o + L.d * (L.h.distance - kOffset);
+        // applyRayColor (K/kernel.h:33-44)
+        L.o = L.point;
+        f3 c = mk3(L.h.color.x, L.h.color.y, L.h.color.z);
+        L.throughput = L.throughput * c;
+        L.radiance = L.radiance + (c * (L.h.emittance * O.emitter_scale)) * L.throughput;
+        if (S.sun_flags & 1) {
+            L.d = sun_sample(S, L.rng);
+            L.h.emittance = rt_fabs(dot(L.d, L.h.normal));
+            L.shadow_emit = L.h.emittance;
+            L.shadow = true;
+            bounce = false;
+        }
+    } else {
+        L.shadow = false;
+    }
+    if (bounce) {
+        // nextPath (K/kernel.h:46-98)
+        L.o = L.point;
+        L.d = diffuse_bounce(L.h.normal, L.rng);
+        L.o = L.o + L.d * kOffset;
+        L.depth += 1;
+        L.h.distance = rt_inf();
+        if (!(L.depth < O.max_depth)) return ST_NEXT;
+    }
+    return ST_SETUP;
+}
+
+// SHADE, part 2, called from wave-uniform control flow (the pixel pool must be updated by the whole
+// wave): accumulate finished paths, hand out pixels, start the next sample of every lane in ST_NEXT.
+template <bool WIDE>
+DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, const PassSeeds& P, WorkQueue Q,
+                    PixelPool& pool, float* __restrict__ res, LaneState& L, int st, bool fresh) {
+    const bool nxt = st == ST_NEXT;
     bool need_pixel = fresh;
-    if (!fresh) {
-        // ---- finish closestIntersect (K/kernel.h:14-24) ----
-        bool hit = L.oct_hit;
-        if (!L.shadow) {
-            if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, L.o, L.d, L.h, stack);
-            if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, L.o, L.d, L.h, stack);
-        } else if (!hit && (!S.world_bvh_empty || !S.actor_bvh_empty)) {
-            Hit sh = L.h;
-            if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, L.o, L.d, sh, stack);
-            if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, L.o, L.d, sh, stack);
-        }
-        bool bounce = false, path_done = false;
-        if (!L.shadow) {
-            if (!hit) {
-                L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, 1.0f);
-                path_done = true;
-            } else {
-                L.point = L.o + L.d * (L.h.distance - kOffset);
-                // applyRayColor (K/kernel.h:33-44)
-                L.o = L.point;
-                f3 c = mk3(L.h.color.x, L.h.color.y, L.h.color.z);
-                L.throughput = L.throughput * c;
-                L.radiance = L.radiance + (c * (L.h.emittance * O.emitter_scale)) * L.throughput;
-                if (S.sun_flags & 1) {
-                    L.d = sun_sample(S, L.rng);
-                    L.h.emittance = rt_fabs(dot(L.d, L.h.normal));
-                    L.shadow_emit = L.h.emittance;
-                    L.shadow = true;
-                    return trace_setup(S, L);
-                }
-                bounce = true;
-            }
-        } else {
-            if (!hit) L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, L.shadow_emit);
-            L.shadow = false;
-            bounce = true;
-        }
-        if (bounce) {
-            // nextPath (K/kernel.h:46-98)
-            L.o = L.point;
-            L.d = diffuse_bounce(L.h.normal, L.rng);
-            L.o = L.o + L.d * kOffset;
-            L.depth += 1;
-            L.h.distance = rt_inf();
-            if (L.depth < O.max_depth) return trace_setup(S, L);
-            path_done = true;
-        }
+    if (nxt && !fresh) {
         // ---- accumulate (K/rayTracer.cl:109-112) ----
         int spp = P.first_spp + L.pass;
         float fs = (float)spp, fs1 = (float)(spp + 1);
@@ -378,8 +415,9 @@ DEV int shade_phase(const SceneView& S, const CameraView& C, const RenderOpts& O
             need_pixel = true;
         }
     }
+    const int slot = claim_slot(Q, pool, need_pixel);  // convergent: every lane of the wave is here
+    if (!nxt) return st;
     if (need_pixel) {
-        int slot = atomicAdd(Q.next, 1);
         int gid = slot < T.n_local ? shard_gid(T, slot) : C.width * C.height;
         if (gid >= C.width * C.height) return ST_DONE;
         L.gid = gid;
@@ -388,11 +426,10 @@ DEV int shade_phase(const SceneView& S, const CameraView& C, const RenderOpts& O
         L.mean = mk3(px[0], px[1], px[2]);
     }
     // ---- new sample (K/rayTracer.cl:55-91) ----
-    L.rng = (unsigned)P.seed[L.pass] + (unsigned)L.gid;
-    rt_pcg_next(&L.rng);
     {
         // locals, not struct members, as out-parameters: keeps LaneState promotable to registers
-        unsigned rng = L.rng;
+        unsigned rng = (unsigned)P.seed[L.pass] + (unsigned)L.gid;
+        rt_pcg_next(&rng);
         f3 o, d;
         primary_ray(C, L.gid, rng, false, o, d);
         L.rng = rng;
@@ -404,12 +441,15 @@ DEV int shade_phase(const SceneView& S, const CameraView& C, const RenderOpts& O
     L.depth = 0;
     L.shadow = false;
     L.h.distance = rt_inf();
-    return trace_setup(S, L);
+    return ST_SETUP;
 }
 
-template <bool WIDE>
+// STATS = true adds a per-phase profile of the state machine (executions, active lanes, shader
+// cycles by s_memtime), summed over waves into stats[phase*3 + {0,1,2}]; used by tools/phase_stats.py.
+template <bool WIDE, bool STATS>
 __global__ void __launch_bounds__(256, 4) render_waves(SceneView S, CameraView C, RenderOpts O, ShardView T, PassSeeds P,
-                                                     WorkQueue Q, float* __restrict__ res) {
+                                                        WorkQueue Q, float* __restrict__ res,
+                                                        unsigned long long* __restrict__ stats) {
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
     LaneState L;
@@ -424,20 +464,44 @@ __global__ void __launch_bounds__(256, 4) render_waves(SceneView S, CameraView C
     L.pass = 0;
     L.gid = 0;
     L.mean = mk3(0, 0, 0);
-    int st = shade_phase<WIDE>(S, C, O, T, P, Q, res, L, stack, true);
+    unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    PixelPool pool{0, 0};
+    int st = next_sample<WIDE>(S, C, T, P, Q, pool, res, L, ST_NEXT, true);
+    if (st == ST_SETUP) st = trace_setup(S, L);
     for (;;) {
         const int n_march = __popcll(__ballot(st == ST_MARCH));
         const int n_block = __popcll(__ballot(st == ST_BLOCK));
         const int n_shade = __popcll(__ballot(st == ST_SHADE));
         if ((n_march | n_block | n_shade) == 0) break;
+        unsigned long long t0 = 0;
+        if (STATS) t0 = __builtin_amdgcn_s_memtime();
+        int ph;
         if (n_march >= n_block && n_march >= n_shade) {
+            ph = 0;
             if (st == ST_MARCH) st = march_phase<WIDE>(S, O, L);
         } else if (n_block >= n_shade) {
+            ph = 1;
             if (st == ST_BLOCK) st = block_phase<WIDE>(S, L);
         } else {
-            if (st == ST_SHADE) st = shade_phase<WIDE>(S, C, O, T, P, Q, res, L, stack, false);
+            ph = 2;
+            if (st == ST_SHADE) st = shade_phase<WIDE>(S, O, L, stack);
+            if (__ballot(st == ST_NEXT)) st = next_sample<WIDE>(S, C, T, P, Q, pool, res, L, st, false);
+            if (st == ST_SETUP) st = trace_setup(S, L);
+        }
+        if (STATS) {
+            unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
+            int n = ph == 0 ? n_march : (ph == 1 ? n_block : n_shade);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (ph == k) {
+                    prof[3 * k] += 1;
+                    prof[3 * k + 1] += (unsigned long long)n;
+                    prof[3 * k + 2] += dt;
+                }
         }
     }
+    if (STATS && (threadIdx.x & 63) == 0)
+        for (int k = 0; k < 9; k++) atomicAdd(&stats[k], prof[k]);
 }
 
 template <bool WIDE>
@@ -539,6 +603,7 @@ static size_t stack_lds_bytes(const SceneView& S, int block) {
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream) {
     if (!(variant & 2) && work_counter) {
+        const bool stats = (variant & 4) != 0;  // work_counter[2..] = 9 x u64 phase profile
         // wave-scheduled persistent kernel: one resident grid, lanes pull pixels from a counter
         const int block = 256;
         static int blocks_per_cu[2] = {0, 0};
@@ -553,8 +618,8 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         }
         int& bpc = blocks_per_cu[wide ? 1 : 0];
         int occ = 0;
-        hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_waves<true>, block, lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_waves<false>, block, lds);
+        hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_waves<true, false>, block, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_waves<false, false>, block, lds);
         if (e != hipSuccess) return e;
         bpc = occ > 0 ? occ : 1;
         int want = (T.n_local + block - 1) / block;
@@ -564,10 +629,13 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
         WorkQueue Q{work_counter};
-        if (wide)
-            hipLaunchKernelGGL(render_waves<true>, dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res);
+        unsigned long long* st = (unsigned long long*)(work_counter + 2);
+        if (stats)
+            hipLaunchKernelGGL((render_waves<true, true>), dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res, st);
+        else if (wide)
+            hipLaunchKernelGGL((render_waves<true, false>), dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res, st);
         else
-            hipLaunchKernelGGL(render_waves<false>, dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res);
+            hipLaunchKernelGGL((render_waves<false, false>), dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res, st);
         return hipGetLastError();
     }
     const int block = 256;

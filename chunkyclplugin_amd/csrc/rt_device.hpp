@@ -69,6 +69,10 @@ struct SceneView {
     const uint32_t* __restrict__ wide;
     int wide_nlev;
     int wide_shift[6], wide_bits[6];
+    // per block (index = block pointer / 2) 8 ints: {modelType, modelPointer, material words 0..4 of a
+    // full cube (K/material.h:31-40), 0} — the block-palette and material-palette reads of
+    // K/block.h:36-49 as ONE 32-byte load; built at upload, null when a palette is missing
+    const int4* __restrict__ block_info;
 };
 
 struct CameraView {
@@ -149,9 +153,14 @@ DEV uint32_t atlas_texel(const SceneView& S, float u, float v, int location, int
 
 // K/material.h:31-82.  `shade` = false skips the writes that only matter to the main record
 // (shadow rays need the accept/reject decision only).
+DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsigned tex_size, unsigned color_w,
+                       unsigned ne, float u, float v, Hit& h);
 DEV bool material_sample(const SceneView& S, int material, float u, float v, Hit& h) {
     const int* m = S.materials + material;
-    unsigned flags = m[0], tint = m[1], tex_size = m[2], color_w = m[3], ne = m[4];
+    return material_eval(S, m[0], m[1], m[2], m[3], m[4], u, v, h);
+}
+DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsigned tex_size, unsigned color_w,
+                       unsigned ne, float u, float v, Hit& h) {
     f4 c = (flags & 4) ? unpack_unorm8(atlas_texel(S, u, v, (int)color_w, (int)tex_size)) : color_from_argb(color_w);
     if (!(c.w > kEps)) return false;
     unsigned tt = tint >> 24;
@@ -200,13 +209,15 @@ DEV Face face_map2(const Slabs& s, float tmin, f3 p) {  // AABB_full_intersect_m
 // Full cube (block model type 1) — K/block.h:48-65 with K/primitives.h:66-112.
 // `no` = march position minus d*OFFSET minus the block corner; the reference passes the march
 // position `pos` where a direction is expected (K/block.h:52), so the UV point is no + tmin*pos.
-DEV float cube_hit(const SceneView& S, int material, f3 no, f3 pos, f3 inv, Hit& h) {
+// The material arrives as its 5 words (read from the material palette, or inline in block_info).
+DEV float cube_hit(const SceneView& S, unsigned m0, unsigned m1, unsigned m2, unsigned m3, unsigned m4, f3 no, f3 pos,
+                   f3 inv, Hit& h) {
     Slabs s = slabs(0, 1, 0, 1, 0, 1, no, inv);
     float tn = slab_near(s), tf = slab_far(s);
     if (tf < tn) return rt_nan();
     Face f = face_unit(s, tn, no + pos * tn);
     h.normal = f.n;  // written before the material test (K/block.h:59-60)
-    return material_sample(S, material, f.u, f.v, h) ? tn - kOffset : rt_nan();
+    return material_eval(S, m0, m1, m2, m3, m4, f.u, f.v, h) ? tn - kOffset : rt_nan();
 }
 
 // AABB model (type 2) — K/block.h:66-91, K/primitives.h:165-260
@@ -280,10 +291,22 @@ DEV float quad_model_hit(const SceneView& S, int ptr, f3 no, f3 dir, Hit& h) {
 // BlockPalette_intersectBlock — K/block.h:30-118.  bx/by/bz = integer cell of the march point.
 DEV float block_hit(const SceneView& S, int block, int bx, int by, int bz, f3 pos, f3 dir, f3 inv, Hit& h) {
     if (block == kAnyType) return rt_nan();
-    int type = S.blocks[block], ptr = S.blocks[block + 1];
     f3 no = (pos - dir * kOffset) - mk3((float)bx, (float)by, (float)bz);
+    int type, ptr;
+    if (S.block_info) {
+        const int4 a = S.block_info[(unsigned)block], b = S.block_info[(unsigned)block + 1u];
+        type = a.x;
+        ptr = a.y;
+        if (type == 1) return cube_hit(S, a.z, a.w, b.x, b.y, b.z, no, pos, inv, h);
+    } else {
+        type = S.blocks[block];
+        ptr = S.blocks[block + 1];
+        if (type == 1) {
+            const int* m = S.materials + ptr;
+            return cube_hit(S, m[0], m[1], m[2], m[3], m[4], no, pos, inv, h);
+        }
+    }
     switch (type) {
-        case 1: return cube_hit(S, ptr, no, pos, inv, h);
         case 2: return aabb_model_hit(S, ptr, no, dir, inv, h);
         case 3: return quad_model_hit(S, ptr, no, dir, h);
         default: return rt_nan();

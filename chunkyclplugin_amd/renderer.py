@@ -182,6 +182,13 @@ class HipPathTracingRenderer:
         check(native.lib().chunky_render_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def phase_stats(self, reset: bool = True) -> dict:
+        out = np.zeros(9, np.uint64)
+        check(native.lib().chunky_render_phase_stats(self._h, ptr(out), 1 if reset else 0))
+        o = out.reshape(3, 3)
+        return {name: {"execs": int(o[i, 0]), "lanes": int(o[i, 1]), "cycles": int(o[i, 2])}
+                for i, name in enumerate(("march", "block", "shade"))}
+
     def preview(self) -> np.ndarray:
         out = np.empty(self.width * self.height, np.int32)
         check(native.lib().chunky_render_preview(self._h, ptr(out)))

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-phase profile of the wave-scheduled kernel on the bench workload (GPU box)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chunkyclplugin_amd import native, scenes  # noqa: E402
+from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance  # noqa: E402
+
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+sc = scenes.cached_outdoor_world(chunks=32, height=256)
+loader = HipSceneLoader(RendererInstance.get(0))
+loader.load_packed(sc)
+r = HipPathTracingRenderer(loader, sc.width, sc.height)
+r.set_camera(sc.projector_type, sc.camera)
+r.set_option(native.OPT_KERNEL, variant)
+seeds = native.java_random_ints(2 * passes)
+r.render_passes(seeds[:passes])
+r.phase_stats(reset=True)
+r.kernel_time()
+r.render_passes(seeds[passes:], first_buffer_spp=passes)
+ms, n = r.kernel_time()
+st = r.phase_stats()
+samples = sc.width * sc.height * passes
+tot = sum(v["cycles"] for v in st.values())
+out = {"variant": variant, "launch_ms": ms / n, "Msamples/s": samples / (ms / n) / 1e3}
+for k, v in st.items():
+    out[k] = {"execs_per_sample": v["execs"] * 64 / samples, "lanes_per_exec": v["lanes"] / max(v["execs"], 1),
+              "cycles_per_exec": v["cycles"] / max(v["execs"], 1), "time_share": v["cycles"] / max(tot, 1)}
+print(json.dumps(out, indent=1))
