@@ -76,7 +76,8 @@ struct chunky_scene {
     chunky_ctx* ctx = nullptr;
     DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info;
     std::vector<int32_t> host_blocks, host_materials;  // kept to rebuild block_info when either changes
-    WideTree wide_meta;  // data vector released after upload; nlev == 0 when absent
+    WideTree wide_meta;  // host copy kept so the kind bits can follow the block palette; nlev == 0 when absent
+    bool wide_dirty = false;
     int octree_depth = -1;
     int atlas_w = 0, atlas_h = 0, atlas_layers = 0;
     int sky_w = 0, sky_h = 0;
@@ -216,10 +217,8 @@ extern "C" int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree,
     const char* why = "";
     WideTree wt;
     if (build_wide_tree(tree, n, depth, bits, nlev, &wt, &why)) {
-        HIP_TRY(scene->wide.upload(wt.data.data(), wt.data.size() * 4, scene->ctx->stream));
-        wt.data.clear();
-        wt.data.shrink_to_fit();
-        scene->wide_meta = wt;
+        scene->wide_meta = std::move(wt);
+        scene->wide_dirty = true;  // annotated + uploaded by scene_view once the block palette is known
     }
     return CHUNKY_OK;
 }
@@ -251,6 +250,7 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
     HIP_TRY(dst->upload(data, (size_t)n * 4, scene->ctx->stream));
     if (kind == CHUNKY_PALETTE_BLOCK || kind == CHUNKY_PALETTE_MATERIAL) {
         (kind == CHUNKY_PALETTE_BLOCK ? scene->host_blocks : scene->host_materials).assign(data, data + n);
+        if (kind == CHUNKY_PALETTE_BLOCK) scene->wide_dirty = true;
         // block_info: per block {type, pointer, 5 material words of a full cube, 0} (rt_device.hpp)
         const std::vector<int32_t>&B = scene->host_blocks, &M = scene->host_materials;
         scene->block_info.release();
@@ -330,7 +330,10 @@ extern "C" int chunky_scene_write_atlas_tile(chunky_scene* scene, int x, int y, 
 extern "C" int chunky_scene_set_sky(chunky_scene* scene, const uint8_t* rgba, int w, int h, float intensity) {
     LOCK_SCENE(scene);
     if (!rgba || w <= 0 || h <= 0) return fail(CHUNKY_E_INVALID, "set_sky: bad texture");
-    HIP_TRY(scene->sky.upload(rgba, (size_t)w * h * 4, scene->ctx->stream));
+    // texels are converted once here with the same rt_unorm8 the kernels would apply per sample
+    std::vector<float> texels((size_t)w * h * 4);
+    for (size_t i = 0; i < texels.size(); i++) texels[i] = rt_unorm8(rgba[i]);
+    HIP_TRY(scene->sky.upload(texels.data(), texels.size() * 4, scene->ctx->stream));
     scene->sky_w = w;
     scene->sky_h = h;
     scene->sky_intensity = intensity;
@@ -353,7 +356,7 @@ static float bits_to_float(int32_t i) {
 
 // Assemble the kernel-side view; Sun_new (K/sky.h:19-40) is evaluated here, on the host, with the
 // same rt_math.h the device uses.
-static int scene_view(const chunky_scene* s, SceneView* v) {
+static int scene_view(chunky_scene* s, SceneView* v) {
     if (!s->octree.p || s->octree_depth < 0) return fail(CHUNKY_E_STATE, "scene has no octree");
     if (!s->blocks.p || !s->materials.p) return fail(CHUNKY_E_STATE, "scene has no block/material palette");
     if (!s->atlas.p) return fail(CHUNKY_E_STATE, "scene has no texture atlas");
@@ -369,7 +372,7 @@ static int scene_view(const chunky_scene* s, SceneView* v) {
     v->trigs = (const int*)s->trigs.p;
     v->atlas = (const uint32_t*)s->atlas.p;
     v->materials = (const int*)s->materials.p;
-    v->sky = (const uint32_t*)s->sky.p;
+    v->sky = (const float4*)s->sky.p;
     v->octree_depth = s->octree_depth;
     v->atlas_w = s->atlas_w;
     v->atlas_h = s->atlas_h;
@@ -399,6 +402,12 @@ static int scene_view(const chunky_scene* s, SceneView* v) {
     v->sun_radius_cos = rt_cos(0.03f);
     v->world_bvh_empty = (s->world_empty || !s->world_bvh.p) ? 1 : 0;
     v->actor_bvh_empty = (s->actor_empty || !s->actor_bvh.p) ? 1 : 0;
+    if (s->wide_dirty && s->wide_meta.nlev > 0) {
+        annotate_wide_tree(&s->wide_meta, s->host_blocks.data(), (int64_t)s->host_blocks.size());
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));  // queued passes may still read the old copy
+        HIP_TRY(s->wide.upload(s->wide_meta.data.data(), s->wide_meta.data.size() * 4, s->ctx->stream));
+        s->wide_dirty = false;
+    }
     v->block_info = (const int4*)s->block_info.p;
     v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;
     v->wide_nlev = s->wide_meta.nlev;
@@ -751,7 +760,7 @@ extern "C" int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int d
         if (e >= 0) return fail(CHUNKY_E_INVALID, "wide tree: lookup did not end in a leaf");
         level_out[i] = (e >> 27) & 15;
         uint32_t code = (uint32_t)e & kWideAny;
-        data_out[i] = code == kWideAny ? 0x7FFFFFFE : (int32_t)code;
+        data_out[i] = code == kWideAny ? 0x7FFFFFFE : (int32_t)(code & kWidePtrMask);
     }
     return CHUNKY_OK;
 }

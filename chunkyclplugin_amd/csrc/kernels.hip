@@ -8,6 +8,8 @@
 // Compiled with -ffp-contract=off (see rt_device.hpp).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "rt_device.hpp"
 
@@ -24,8 +26,10 @@ struct LdsStack {
 // Leaf lookup of K/octree.h:81-89: cell (bx,by,bz) -> block pointer `data` and leaf `level`.
 // WIDE = false walks the reference layout from the root, one bit per level; WIDE = true walks the
 // wide re-layout (widetree.hpp), bits[i] bits per level — same (data, level) for every cell.
+// `kind`: 0 full cube, 1 other model, 2 cannot be hit (air, invisible, ANY_TYPE); the reference
+// layout carries no kinds, so every non-air leaf reports 1 there (the general test handles all types).
 template <bool WIDE>
-DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level) {
+DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind) {
     if (!WIDE) {
         const int* __restrict__ tree = S.octree;
         level = S.octree_depth;
@@ -35,6 +39,7 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
             data = tree[data + ((((bx >> level) & 1) << 2) | (((by >> level) & 1) << 1) | ((bz >> level) & 1))];
         }
         data = -data;
+        kind = (data == 0 || data == kAnyType) ? 2 : 1;
     } else {
         const uint32_t* __restrict__ tree = S.wide;
         int e = 0;
@@ -48,8 +53,10 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
             }
         }
         level = (e >> 27) & 15;
-        unsigned code = (unsigned)e & 0x7FFFFFFu;
-        data = code == 0x7FFFFFFu ? kAnyType : (int)code;
+        const unsigned code = (unsigned)e & 0x7FFFFFFu;
+        data = code == 0x7FFFFFFu ? kAnyType : (int)(code & 0x1FFFFFFu);
+        kind = (code & 0x1FFFFFFu) == 0 ? 2 : (int)(code >> 25);
+        if (kind == 3) kind = 2;
     }
 }
 
@@ -73,9 +80,9 @@ DEV bool octree_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h) {
         f3 po = pos + off;
         int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
         if (((bx | by | bz) >> depth) != 0) return false;  // any coordinate outside [0, 2^depth)
-        int level, data;
-        leaf_lookup<WIDE>(S, bx, by, bz, data, level);
-        if (data != 0) {  // ray->material is always 0 (K/wavefront.h:34, K/octree.h:92)
+        int level, data, kind;
+        leaf_lookup<WIDE>(S, bx, by, bz, data, level, kind);
+        if (kind != 2) {  // not air (ray->material is always 0, K/octree.h:92) and able to intersect
             float dist = block_hit(S, data, bx, by, bz, pos, d, inv, h);
             if (dist == dist) {
                 h.distance = dist_march + dist;
@@ -273,9 +280,9 @@ DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     f3 po = pos + L.d * kOffset;
     int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
     if (((bx | by | bz) >> depth) != 0) return ST_SHADE;
-    int level, data;
-    leaf_lookup<WIDE>(S, bx, by, bz, data, level);
-    if (data != 0 && data != kAnyType) {
+    int level, data, kind;
+    leaf_lookup<WIDE>(S, bx, by, bz, data, level, kind);
+    if (kind != 2) {
         L.cand_data = data;
         L.cand_level = level;
         return ST_BLOCK;
@@ -609,7 +616,8 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         static int blocks_per_cu[2] = {0, 0};
         static int n_cu = 0;
         const bool wide = use_wide(variant, S);
-        const size_t lds = stack_lds_bytes(S, block);
+        size_t lds = stack_lds_bytes(S, block);
+        if (const char* pad = getenv("CHUNKY_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments
         if (n_cu == 0) {
             int dev = 0;
             hipDeviceProp_t prop;

@@ -54,7 +54,7 @@ struct SceneView {
     const int* __restrict__ trigs;    // :24
     const uint32_t* __restrict__ atlas;  // :26  RGBA8 texels as little-endian uint32, [layer][y][x]
     const int* __restrict__ materials;   // :27
-    const uint32_t* __restrict__ sky;    // :29  RGBA8 [y][x]
+    const float4* __restrict__ sky;      // :29  [y][x], UNORM8 texels already converted (rt_unorm8) at upload
     int octree_depth;
     int atlas_w, atlas_h, atlas_layers;
     int sky_w, sky_h;
@@ -414,16 +414,14 @@ DEV f4 sky_color(const SceneView& S, f3 d) {
     float a, b;
     rt_mirror_linear(theta, S.sky_w, &i0, &i1, &a);
     rt_mirror_linear(phi, S.sky_h, &j0, &j1, &b);
-    f4 t00 = unpack_unorm8(S.sky[j0 * S.sky_w + i0]);
-    f4 t10 = unpack_unorm8(S.sky[j0 * S.sky_w + i1]);
-    f4 t01 = unpack_unorm8(S.sky[j1 * S.sky_w + i0]);
-    f4 t11 = unpack_unorm8(S.sky[j1 * S.sky_w + i1]);
+    const float4 t00 = S.sky[j0 * S.sky_w + i0], t10 = S.sky[j0 * S.sky_w + i1];
+    const float4 t01 = S.sky[j1 * S.sky_w + i0], t11 = S.sky[j1 * S.sky_w + i1];
     float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     float k = S.sky_intensity;
+    // the alpha channel is sampled by the reference too but never read again (K/kernel.h:30)
     return f4{(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x) * k,
               (w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y) * k,
-              (w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z) * k,
-              (w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w) * k};
+              (w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z) * k, 0.0f};
 }
 
 // Sun_intersect — K/sky.h:42-66: adds the sun-disc texel (x intensity) to c
@@ -440,7 +438,6 @@ DEV void sun_disc(const SceneView& S, f3 d, f4& c) {
             c.x += t.x * S.sun_intensity;
             c.y += t.y * S.sun_intensity;
             c.z += t.z * S.sun_intensity;
-            c.w += t.w * S.sun_intensity;
         }
     }
 }

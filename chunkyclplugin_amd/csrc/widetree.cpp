@@ -30,7 +30,7 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
                      const char** why) {
     static const char* kDepth = "octree depth outside 0..15";
     static const char* kBits = "level bits do not add up to the octree depth";
-    static const char* kPtr = "block pointer does not fit 27 bits";
+    static const char* kPtr = "block pointer does not fit 25 bits";
     static const char* kTree = "octree node outside the array";
     static const char* kSize = "wide tree would exceed 2^31 entries";
     if (depth < 0 || depth > 15) return *why = kDepth, false;
@@ -70,7 +70,7 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
                         uint32_t code = (uint32_t)(-(int64_t)val);
                         if (code == 0x7FFFFFFEu)
                             code = kWideAny;
-                        else if (code >= kWideAny)
+                        else if (code >= kWidePtrMask)
                             return *why = kPtr, false;
                         d[(size_t)slot] = kWideLeaf | ((uint32_t)lvl << 27) | code;
                     } else {
@@ -85,6 +85,21 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
                 }
     }
     return true;
+}
+
+void annotate_wide_tree(WideTree* t, const int32_t* blocks, int64_t n) {
+    for (uint32_t& e : t->data) {
+        if (!(e & kWideLeaf)) continue;
+        const uint32_t code = e & kWideAny;
+        if (code == kWideAny) continue;
+        const uint32_t ptr = code & kWidePtrMask;
+        uint32_t kind = 2;
+        if (ptr != 0 && (int64_t)ptr + 1 < n) {
+            const int32_t type = blocks[ptr];
+            kind = type == 1 ? 0u : ((type == 2 || type == 3) ? 1u : 2u);
+        }
+        e = (e & ~(3u << kWideKindShift)) | (kind << kWideKindShift);
+    }
 }
 
 }  // namespace chunky

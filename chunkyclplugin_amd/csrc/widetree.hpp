@@ -9,7 +9,10 @@
 //   entry >= 0 : int offset of the child node (level i+1) inside the array
 //   entry <  0 : leaf — bits 30..27 = level of the octree leaf that contains the cell (its cube has
 //                edge 2^level; needed for the leaf-exit box of K/octree.h:103-106),
-//                bits 26..0 = block-palette pointer (K/octree.h:88), 0x7FFFFFF = ANY_TYPE (K/block.h:32)
+//                bits 26..25 = kind of the block (filled in by annotate_wide_tree once the block
+//                palette is known): 0 full cube (K/block.h:48), 1 AABB/quad model (:66,:92),
+//                2 never intersects (model type 0/unknown, K/block.h:44-47), 3 ANY_TYPE (K/block.h:32);
+//                bits 24..0 = block-palette pointer (K/octree.h:88); 0x7FFFFFF = ANY_TYPE
 //
 // With bits = {3,3,3} a depth-9 world needs at most 3 dependent loads per lookup instead of 9.
 #pragma once
@@ -21,6 +24,8 @@ namespace chunky {
 constexpr int kWideMaxLevels = 6;
 constexpr uint32_t kWideLeaf = 0x80000000u;
 constexpr uint32_t kWideAny = 0x7FFFFFFu;
+constexpr uint32_t kWidePtrMask = 0x1FFFFFFu;
+constexpr int kWideKindShift = 25;
 
 struct WideTree {
     std::vector<uint32_t> data;
@@ -33,6 +38,9 @@ struct WideTree {
 // that does not fit 27 bits, or a malformed tree.
 bool build_wide_tree(const int32_t* oct, int64_t n_ints, int depth, const int* level_bits, int nlev, WideTree* out,
                      const char** why);
+
+// Sets the kind bits of every leaf from the block palette (2 ints per block: modelType, pointer).
+void annotate_wide_tree(WideTree* t, const int32_t* block_palette, int64_t n_ints);
 
 // Default split of `depth` address bits into levels: 3 bits per level from the bottom, the
 // remainder (1..3 bits) at the top.
