@@ -349,6 +349,42 @@ DEV int claim_slot(WorkQueue Q, PixelPool& pool, bool need) {
     return slot;
 }
 
+// All launch parameters travel as ONE by-value struct and are read through the kernel-argument
+// segment pointer (constant address space, scalar loads).  The march loop keeps only the handful
+// of fields it needs in SGPRs; the BLOCK and SHADE phases re-read theirs through a pointer the
+// optimiser cannot see through (`fresh_args`), so those ~100 rarely used scalars are not hoisted
+// out of the state-machine loop and spilled into VGPR lanes (v_readlane in the march loop was
+// ~30 % of its VALU issue before this).
+struct WaveArgs {
+    SceneView S;
+    CameraView C;
+    RenderOpts O;
+    ShardView T;
+    PassSeeds P;
+    WorkQueue Q;
+    float* res;
+    unsigned long long* stats;
+};
+typedef const WaveArgs __attribute__((address_space(4))) * WaveArgPtr;
+
+// copy one member struct out of the argument segment (explicit cast: the host pass has no
+// address-space-qualified copy constructors; on the device the loads stay scalar)
+template <typename T>
+DEV T arg_copy(const T __attribute__((address_space(4))) * p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *p;  // constant-address-space struct load: only the fields that are used get (scalar) loads
+#else
+    (void)p;
+    return T{};  // host pass: kernels bodies are parsed but never run
+#endif
+}
+
+DEV WaveArgPtr fresh_args() {
+    WaveArgPtr a = (WaveArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return a;
+}
+
 // SHADE, part 1: everything from the end of a trace to the start of the next one on the same path.
 // Returns ST_SETUP (a ray is ready to be traced) or ST_NEXT (the path is finished).
 template <bool WIDE>
@@ -403,18 +439,21 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
 // SHADE, part 2, called from wave-uniform control flow (the pixel pool must be updated by the whole
 // wave): accumulate finished paths, hand out pixels, start the next sample of every lane in ST_NEXT.
 template <bool WIDE>
-DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, const PassSeeds& P, WorkQueue Q,
-                    PixelPool& pool, float* __restrict__ res, LaneState& L, int st, bool fresh) {
+DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, WaveArgPtr A, PixelPool& pool,
+                    LaneState& L, int st, bool fresh) {
+    const int first_spp = A->P.first_spp, n_passes = A->P.n;
+    float* __restrict__ res = A->res;
+    WorkQueue Q = arg_copy(&A->Q);
     const bool nxt = st == ST_NEXT;
     bool need_pixel = fresh;
     if (nxt && !fresh) {
         // ---- accumulate (K/rayTracer.cl:109-112) ----
-        int spp = P.first_spp + L.pass;
+        int spp = first_spp + L.pass;
         float fs = (float)spp, fs1 = (float)(spp + 1);
         L.mean = f3{(L.mean.x * fs + L.radiance.x) / fs1, (L.mean.y * fs + L.radiance.y) / fs1,
                     (L.mean.z * fs + L.radiance.z) / fs1};
         L.pass += 1;
-        if (L.pass >= P.n) {
+        if (L.pass >= n_passes) {
             float* px = res + 3 * (size_t)L.gid;
             px[0] = L.mean.x;
             px[1] = L.mean.y;
@@ -435,7 +474,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
     // ---- new sample (K/rayTracer.cl:55-91) ----
     {
         // locals, not struct members, as out-parameters: keeps LaneState promotable to registers
-        unsigned rng = (unsigned)P.seed[L.pass] + (unsigned)L.gid;
+        unsigned rng = (unsigned)A->P.seed[L.pass] + (unsigned)L.gid;  // per-lane index: a vector load from the argument segment
         rt_pcg_next(&rng);
         f3 o, d;
         primary_ray(C, L.gid, rng, false, o, d);
@@ -454,11 +493,12 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
 // STATS = true adds a per-phase profile of the state machine (executions, active lanes, shader
 // cycles by s_memtime), summed over waves into stats[phase*3 + {0,1,2}]; used by tools/phase_stats.py.
 template <bool WIDE, bool STATS>
-__global__ void __launch_bounds__(256, 4) render_waves(SceneView S, CameraView C, RenderOpts O, ShardView T, PassSeeds P,
-                                                        WorkQueue Q, float* __restrict__ res,
-                                                        unsigned long long* __restrict__ stats) {
+__global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) {
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
+    // hot subset for MARCH (the rest of these copies is dead and never loaded)
+    const SceneView Sm = arg_copy(&fresh_args()->S);
+    const RenderOpts Om = arg_copy(&fresh_args()->O);
     LaneState L;
     L.h.material = 0;
     L.h.normal = mk3(0, 0, 0);
@@ -473,8 +513,15 @@ __global__ void __launch_bounds__(256, 4) render_waves(SceneView S, CameraView C
     L.mean = mk3(0, 0, 0);
     unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     PixelPool pool{0, 0};
-    int st = next_sample<WIDE>(S, C, T, P, Q, pool, res, L, ST_NEXT, true);
-    if (st == ST_SETUP) st = trace_setup(S, L);
+    int st;
+    {
+        WaveArgPtr A = fresh_args();
+        const SceneView S = arg_copy(&A->S);
+        const CameraView C = arg_copy(&A->C);
+        const ShardView T = arg_copy(&A->T);
+        st = next_sample<WIDE>(S, C, T, A, pool, L, ST_NEXT, true);
+        if (st == ST_SETUP) st = trace_setup(S, L);
+    }
     for (;;) {
         const int n_march = __popcll(__ballot(st == ST_MARCH));
         const int n_block = __popcll(__ballot(st == ST_BLOCK));
@@ -485,14 +532,22 @@ __global__ void __launch_bounds__(256, 4) render_waves(SceneView S, CameraView C
         int ph;
         if (n_march >= n_block && n_march >= n_shade) {
             ph = 0;
-            if (st == ST_MARCH) st = march_phase<WIDE>(S, O, L);
+            if (st == ST_MARCH) st = march_phase<WIDE>(Sm, Om, L);
         } else if (n_block >= n_shade) {
             ph = 1;
+            const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_BLOCK) st = block_phase<WIDE>(S, L);
         } else {
             ph = 2;
+            WaveArgPtr A = fresh_args();
+            const SceneView S = arg_copy(&A->S);
+            const RenderOpts O = arg_copy(&A->O);
             if (st == ST_SHADE) st = shade_phase<WIDE>(S, O, L, stack);
-            if (__ballot(st == ST_NEXT)) st = next_sample<WIDE>(S, C, T, P, Q, pool, res, L, st, false);
+            if (__ballot(st == ST_NEXT)) {
+                const CameraView C = arg_copy(&A->C);
+                const ShardView T = arg_copy(&A->T);
+                st = next_sample<WIDE>(S, C, T, A, pool, L, st, false);
+            }
             if (st == ST_SETUP) st = trace_setup(S, L);
         }
         if (STATS) {
@@ -507,8 +562,10 @@ __global__ void __launch_bounds__(256, 4) render_waves(SceneView S, CameraView C
                 }
         }
     }
-    if (STATS && (threadIdx.x & 63) == 0)
+    if (STATS && (threadIdx.x & 63) == 0) {
+        unsigned long long* stats = fresh_args()->stats;
         for (int k = 0; k < 9; k++) atomicAdd(&stats[k], prof[k]);
+    }
 }
 
 template <bool WIDE>
@@ -636,14 +693,13 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         if (grid <= 0 || P.n <= 0) return hipSuccess;
         e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
-        WorkQueue Q{work_counter};
-        unsigned long long* st = (unsigned long long*)(work_counter + 2);
+        WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2)};
         if (stats)
-            hipLaunchKernelGGL((render_waves<true, true>), dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res, st);
+            hipLaunchKernelGGL((render_waves<true, true>), dim3(grid), dim3(block), lds, stream, A);
         else if (wide)
-            hipLaunchKernelGGL((render_waves<true, false>), dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res, st);
+            hipLaunchKernelGGL((render_waves<true, false>), dim3(grid), dim3(block), lds, stream, A);
         else
-            hipLaunchKernelGGL((render_waves<false, false>), dim3(grid), dim3(block), lds, stream, S, C, O, T, P, Q, res, st);
+            hipLaunchKernelGGL((render_waves<false, false>), dim3(grid), dim3(block), lds, stream, A);
         return hipGetLastError();
     }
     const int block = 256;
