@@ -24,13 +24,14 @@ struct LdsStack {
 };
 
 // Leaf lookup of K/octree.h:81-89: cell (bx,by,bz) -> block pointer `data` and leaf `level`.
-// WIDE = false walks the reference layout from the root, one bit per level; WIDE = true walks the
-// wide re-layout (widetree.hpp), bits[i] bits per level — same (data, level) for every cell.
+// TREE = 0 walks the reference layout from the root, one bit per level; TREE = -1 walks the wide
+// re-layout (widetree.hpp) with per-level bit counts from the scene view; TREE = n > 0 walks a wide
+// tree of n levels of 3 bits (compile-time shifts) — same (data, level) for every cell.
 // `kind`: 0 full cube, 1 other model, 2 cannot be hit (air, invisible, ANY_TYPE); the reference
 // layout carries no kinds, so every non-air leaf reports 1 there (the general test handles all types).
-template <bool WIDE>
+template <int TREE>
 DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind) {
-    if (!WIDE) {
+    if (TREE == 0) {
         const int* __restrict__ tree = S.octree;
         level = S.octree_depth;
         data = tree[0];
@@ -43,6 +44,16 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
     } else {
         const uint32_t* __restrict__ tree = S.wide;
         int e = 0;
+        if (TREE > 0) {
+#pragma unroll
+            for (int i = 0; i < TREE; i++) {
+                if (i == 0 || e >= 0) {
+                    const int sh = 3 * (TREE - 1 - i);
+                    const unsigned idx = (((unsigned)bx >> sh) & 7u) << 6 | (((unsigned)by >> sh) & 7u) << 3 | (((unsigned)bz >> sh) & 7u);
+                    e = (int)tree[(unsigned)e + idx];
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             if (i < S.wide_nlev && e >= 0) {
@@ -61,7 +72,7 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
 }
 
 // Octree_octreeIntersect — K/octree.h:41-109.  Leaf-exit march.
-template <bool WIDE>
+template <int TREE>
 DEV bool octree_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h) {
     const int depth = S.octree_depth;
     float dist_march = 0;
@@ -81,7 +92,7 @@ DEV bool octree_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h) {
         int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
         if (((bx | by | bz) >> depth) != 0) return false;  // any coordinate outside [0, 2^depth)
         int level, data, kind;
-        leaf_lookup<WIDE>(S, bx, by, bz, data, level, kind);
+        leaf_lookup<TREE>(S, bx, by, bz, data, level, kind);
         if (kind != 2) {  // not air (ray->material is always 0, K/octree.h:92) and able to intersect
             float dist = block_hit(S, data, bx, by, bz, pos, d, inv, h);
             if (dist == dist) {
@@ -101,9 +112,9 @@ DEV bool octree_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h) {
 }
 
 // closestIntersect — K/kernel.h:14-24
-template <bool WIDE>
+template <int TREE>
 DEV bool closest_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h, f3& point, LdsStack& stack) {
-    bool hit = octree_hit<WIDE>(S, o, d, draw_depth, h);
+    bool hit = octree_hit<TREE>(S, o, d, draw_depth, h);
     if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, o, d, h, stack);
     if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, o, d, h, stack);
     if (hit) point = o + d * (h.distance - kOffset);
@@ -123,7 +134,7 @@ DEV void put_record(HitRecord* out, int& n, bool hit, const Hit& h, f3 point) {
 }
 
 // One sample — K/rayTracer.cl:55-107
-template <bool RECORD, bool WIDE>
+template <bool RECORD, int TREE>
 DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O, int seed, int gid, LdsStack& stack,
                    HitRecord* rec_out, int* rec_n) {
     unsigned rng = (unsigned)seed + (unsigned)gid;
@@ -140,7 +151,7 @@ DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O,
     f3 point = mk3(0, 0, 0);
     int depth = 0, nrec = 0;
     for (;;) {
-        bool hit = closest_hit<WIDE>(S, o, d, O.draw_depth, h, point, stack);
+        bool hit = closest_hit<TREE>(S, o, d, O.draw_depth, h, point, stack);
         if (RECORD) put_record(rec_out, nrec, hit, h, point);
         if (!hit) {
             radiance = radiance + sky_radiance(S, d, throughput, 1.0f);  // record.emittance = 1
@@ -159,7 +170,7 @@ DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O,
             h.emittance = rt_fabs(dot(d, h.normal));  // written to the main record, then copied (K/sky.h:90)
             Hit sh = h;
             f3 sp = h.normal;  // the copy's dead point = normal (K/wavefront.h:73)
-            bool shadowed = closest_hit<WIDE>(S, o, d, O.draw_depth, sh, sp, stack);
+            bool shadowed = closest_hit<TREE>(S, o, d, O.draw_depth, sh, sp, stack);
             if (RECORD) put_record(rec_out, nrec, shadowed, sh, sp);
             if (!shadowed) radiance = radiance + sky_radiance(S, d, throughput, sh.emittance);
         }
@@ -182,7 +193,7 @@ DEV int shard_gid(const ShardView& T, int local) {
     return (t * T.world + T.rank) * T.tile + w;
 }
 
-template <bool WIDE>
+template <int TREE>
 __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, RenderOpts O, ShardView T, PassSeeds P,
                                                      float* __restrict__ res) {
     extern __shared__ int lds[];
@@ -194,7 +205,7 @@ __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, R
     float* px = res + 3 * (size_t)gid;
     f3 mean = mk3(px[0], px[1], px[2]);
     for (int k = 0; k < P.n; k++) {
-        f3 c = sample_path<false, WIDE>(S, C, O, P.seed[k], gid, stack, nullptr, nullptr);
+        f3 c = sample_path<false, TREE>(S, C, O, P.seed[k], gid, stack, nullptr, nullptr);
         int spp = P.first_spp + k;
         float fs = (float)spp, fs1 = (float)(spp + 1);
         mean = f3{(mean.x * fs + c.x) / fs1, (mean.y * fs + c.y) / fs1, (mean.z * fs + c.z) / fs1};
@@ -246,7 +257,7 @@ struct LaneState {
     f3 point;
 };
 
-template <bool WIDE>
+template <int TREE>
 DEV void leaf_exit(const SceneView& S, LaneState& L, f3 po, int bx, int by, int bz, int level) {
     int lx = bx >> level, ly = by >> level, lz = bz >> level;
     L.dist_march += box_exit((float)(lx << level), (float)((lx + 1) << level), (float)(ly << level),
@@ -272,7 +283,7 @@ DEV int trace_setup(const SceneView& S, LaneState& L) {
     return ST_MARCH;
 }
 
-template <bool WIDE>
+template <int TREE>
 DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     const int depth = S.octree_depth;
     if (L.steps >= O.draw_depth || L.dist_march > L.h.distance) return ST_SHADE;
@@ -281,17 +292,17 @@ DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
     if (((bx | by | bz) >> depth) != 0) return ST_SHADE;
     int level, data, kind;
-    leaf_lookup<WIDE>(S, bx, by, bz, data, level, kind);
+    leaf_lookup<TREE>(S, bx, by, bz, data, level, kind);
     if (kind != 2) {
         L.cand_data = data;
         L.cand_level = level;
         return ST_BLOCK;
     }
-    leaf_exit<WIDE>(S, L, po, bx, by, bz, level);
+    leaf_exit<TREE>(S, L, po, bx, by, bz, level);
     return ST_MARCH;
 }
 
-template <bool WIDE>
+template <int TREE>
 DEV int block_phase(const SceneView& S, LaneState& L) {
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
@@ -311,7 +322,7 @@ DEV int block_phase(const SceneView& S, LaneState& L) {
         L.oct_hit = true;
         return ST_SHADE;
     }
-    leaf_exit<WIDE>(S, L, po, bx, by, bz, L.cand_level);
+    leaf_exit<TREE>(S, L, po, bx, by, bz, L.cand_level);
     return ST_MARCH;
 }
 
@@ -387,7 +398,7 @@ DEV WaveArgPtr fresh_args() {
 
 // SHADE, part 1: everything from the end of a trace to the start of the next one on the same path.
 // Returns ST_SETUP (a ray is ready to be traced) or ST_NEXT (the path is finished).
-template <bool WIDE>
+template <int TREE>
 DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsStack& stack) {
     // ---- finish closestIntersect (K/kernel.h:14-24) ----
     bool hit = L.oct_hit;
@@ -438,7 +449,7 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
 
 // SHADE, part 2, called from wave-uniform control flow (the pixel pool must be updated by the whole
 // wave): accumulate finished paths, hand out pixels, start the next sample of every lane in ST_NEXT.
-template <bool WIDE>
+template <int TREE>
 DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, WaveArgPtr A, PixelPool& pool,
                     LaneState& L, int st, bool fresh) {
     const int first_spp = A->P.first_spp, n_passes = A->P.n;
@@ -492,7 +503,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
 
 // STATS = true adds a per-phase profile of the state machine (executions, active lanes, shader
 // cycles by s_memtime), summed over waves into stats[phase*3 + {0,1,2}]; used by tools/phase_stats.py.
-template <bool WIDE, bool STATS>
+template <int TREE, bool STATS>
 __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) {
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
@@ -519,7 +530,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
         const SceneView S = arg_copy(&A->S);
         const CameraView C = arg_copy(&A->C);
         const ShardView T = arg_copy(&A->T);
-        st = next_sample<WIDE>(S, C, T, A, pool, L, ST_NEXT, true);
+        st = next_sample<TREE>(S, C, T, A, pool, L, ST_NEXT, true);
         if (st == ST_SETUP) st = trace_setup(S, L);
     }
     for (;;) {
@@ -532,21 +543,21 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
         int ph;
         if (n_march >= n_block && n_march >= n_shade) {
             ph = 0;
-            if (st == ST_MARCH) st = march_phase<WIDE>(Sm, Om, L);
+            if (st == ST_MARCH) st = march_phase<TREE>(Sm, Om, L);
         } else if (n_block >= n_shade) {
             ph = 1;
             const SceneView S = arg_copy(&fresh_args()->S);
-            if (st == ST_BLOCK) st = block_phase<WIDE>(S, L);
+            if (st == ST_BLOCK) st = block_phase<TREE>(S, L);
         } else {
             ph = 2;
             WaveArgPtr A = fresh_args();
             const SceneView S = arg_copy(&A->S);
             const RenderOpts O = arg_copy(&A->O);
-            if (st == ST_SHADE) st = shade_phase<WIDE>(S, O, L, stack);
+            if (st == ST_SHADE) st = shade_phase<TREE>(S, O, L, stack);
             if (__ballot(st == ST_NEXT)) {
                 const CameraView C = arg_copy(&A->C);
                 const ShardView T = arg_copy(&A->T);
-                st = next_sample<WIDE>(S, C, T, A, pool, L, st, false);
+                st = next_sample<TREE>(S, C, T, A, pool, L, st, false);
             }
             if (st == ST_SETUP) st = trace_setup(S, L);
         }
@@ -568,7 +579,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
     }
 }
 
-template <bool WIDE>
+template <int TREE>
 __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraView C, RenderOpts O, int seed,
                                                              const int* __restrict__ gids, int n,
                                                              HitRecord* __restrict__ out, int* __restrict__ counts,
@@ -579,7 +590,7 @@ __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraV
     if (i >= n) return;
     HitRecord local[kMaxTraces];
     int cnt = 0;
-    f3 c = sample_path<true, WIDE>(S, C, O, seed, gids[i], stack, local, &cnt);
+    f3 c = sample_path<true, TREE>(S, C, O, seed, gids[i], stack, local, &cnt);
     for (int k = 0; k < cnt; k++) out[(size_t)i * kMaxTraces + k] = local[k];
     counts[i] = cnt;
     radiance[3 * i] = c.x;
@@ -588,7 +599,7 @@ __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraV
 }
 
 // preview — K/rayTracer.cl:115-217
-template <bool WIDE>
+template <int TREE>
 __global__ void __launch_bounds__(256) preview_lanes(SceneView S, CameraView C, RenderOpts O, int* __restrict__ argb) {
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
@@ -612,7 +623,7 @@ __global__ void __launch_bounds__(256) preview_lanes(SceneView S, CameraView C, 
     h.emittance = 0;
     f3 point;
     f4 c;
-    if (closest_hit<WIDE>(S, o, d, O.draw_depth, h, point, stack)) {
+    if (closest_hit<TREE>(S, o, d, O.draw_depth, h, point, stack)) {
         float shading = dot(h.normal, mk3(0.25f, 0.866f, 0.433f));
         shading = rt_fmax(0.3f, shading);
         c = f4{h.color.x * shading, h.color.y * shading, h.color.z * shading, 0};
@@ -670,7 +681,6 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         const bool stats = (variant & 4) != 0;  // work_counter[2..] = 9 x u64 phase profile
         // wave-scheduled persistent kernel: one resident grid, lanes pull pixels from a counter
         const int block = 256;
-        static int blocks_per_cu[2] = {0, 0};
         static int n_cu = 0;
         const bool wide = use_wide(variant, S);
         size_t lds = stack_lds_bytes(S, block);
@@ -681,12 +691,29 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
             n_cu = prop.multiProcessorCount;
         }
-        int& bpc = blocks_per_cu[wide ? 1 : 0];
+        // tree kind: 0 reference layout, n = 1..5 wide tree of n 3-bit levels, -1 any other wide split
+        int tree = 0;
+        if (wide) {
+            tree = S.wide_nlev <= 5 ? S.wide_nlev : -1;
+            for (int i = 0; i < S.wide_nlev; i++)
+                if (S.wide_bits[i] != 3) tree = -1;
+        }
+        typedef void (*Kernel)(WaveArgs);
+        Kernel k;
+        switch (stats ? 100 + tree : tree) {
+            case 0: k = render_waves<0, false>; break;
+            case 1: k = render_waves<1, false>; break;
+            case 2: k = render_waves<2, false>; break;
+            case 3: k = render_waves<3, false>; break;
+            case 4: k = render_waves<4, false>; break;
+            case 5: k = render_waves<5, false>; break;
+            case 103: k = render_waves<3, true>; break;
+            default: k = stats ? render_waves<-1, true> : render_waves<-1, false>; break;
+        }
         int occ = 0;
-        hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_waves<true, false>, block, lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, render_waves<false, false>, block, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
         if (e != hipSuccess) return e;
-        bpc = occ > 0 ? occ : 1;
+        int bpc = occ > 0 ? occ : 1;
         int want = (T.n_local + block - 1) / block;
         int grid = n_cu * bpc;
         if (grid > want) grid = want;
@@ -694,21 +721,16 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
         WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2)};
-        if (stats)
-            hipLaunchKernelGGL((render_waves<true, true>), dim3(grid), dim3(block), lds, stream, A);
-        else if (wide)
-            hipLaunchKernelGGL((render_waves<true, false>), dim3(grid), dim3(block), lds, stream, A);
-        else
-            hipLaunchKernelGGL((render_waves<false, false>), dim3(grid), dim3(block), lds, stream, A);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
         return hipGetLastError();
     }
     const int block = 256;
     int grid = (T.n_local + block - 1) / block;
     if (grid <= 0 || P.n <= 0) return hipSuccess;
     if (use_wide(variant, S))
-        hipLaunchKernelGGL(render_lanes<true>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
+        hipLaunchKernelGGL(render_lanes<-1>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
     else
-        hipLaunchKernelGGL(render_lanes<false>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
+        hipLaunchKernelGGL(render_lanes<0>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
     return hipGetLastError();
 }
 
@@ -719,10 +741,10 @@ hipError_t launch_trace_records(int variant, const SceneView& S, const CameraVie
     int grid = (n + block - 1) / block;
     if (grid <= 0) return hipSuccess;
     if (use_wide(variant, S))
-        hipLaunchKernelGGL(trace_records_kernel<true>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O,
+        hipLaunchKernelGGL(trace_records_kernel<-1>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O,
                            seed, gids_dev, n, out, counts, radiance);
     else
-        hipLaunchKernelGGL(trace_records_kernel<false>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O,
+        hipLaunchKernelGGL(trace_records_kernel<0>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O,
                            seed, gids_dev, n, out, counts, radiance);
     return hipGetLastError();
 }
@@ -732,9 +754,9 @@ hipError_t launch_preview(int variant, const SceneView& S, const CameraView& C, 
     const int block = 256;
     int grid = (C.width * C.height + block - 1) / block;
     if (use_wide(variant, S))
-        hipLaunchKernelGGL(preview_lanes<true>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, argb);
+        hipLaunchKernelGGL(preview_lanes<-1>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, argb);
     else
-        hipLaunchKernelGGL(preview_lanes<false>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, argb);
+        hipLaunchKernelGGL(preview_lanes<0>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, argb);
     return hipGetLastError();
 }
 

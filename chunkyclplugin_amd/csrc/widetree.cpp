@@ -6,15 +6,11 @@
 namespace chunky {
 
 int default_wide_levels(int depth, int* level_bits) {
-    if (depth <= 0) {
-        level_bits[0] = 0;
-        return 1;
-    }
-    int nlev = (depth + 2) / 3;
+    // 3 bits at every level; the top level is padded when depth is not a multiple of 3, so the
+    // kernels can use compile-time shifts (a padded top node wastes at most 511 entries)
+    int nlev = depth <= 0 ? 1 : (depth + 2) / 3;
     if (nlev > kWideMaxLevels) nlev = kWideMaxLevels;
-    int rest = depth - 3 * (nlev - 1);
-    level_bits[0] = rest;
-    for (int i = 1; i < nlev; i++) level_bits[i] = 3;
+    for (int i = 0; i < nlev; i++) level_bits[i] = 3;
     return nlev;
 }
 
@@ -36,9 +32,12 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
     if (depth < 0 || depth > 15) return *why = kDepth, false;
     int sum = 0;
     for (int i = 0; i < nlev; i++) sum += level_bits[i];
-    if (nlev < 1 || nlev > kWideMaxLevels || sum != depth) return *why = kBits, false;
+    // the top level may address up to 2 more bits than the world has (padding: those cells are
+    // outside [0, 2^depth) and are never looked up)
+    const int pad = sum - depth;
+    if (nlev < 1 || nlev > kWideMaxLevels || pad < 0 || pad > level_bits[0]) return *why = kBits, false;
     out->nlev = nlev;
-    int s = depth;
+    int s = sum;
     for (int i = 0; i < nlev; i++) {
         s -= level_bits[i];
         out->bits[i] = level_bits[i];
@@ -54,12 +53,14 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
         queue.pop_front();
         const int b = out->bits[j.level], sh = out->shift[j.level];
         const int side = 1 << b;
+        const int real = j.level == 0 ? b - pad : b;  // address bits of this level that exist in the world
         for (int ex = 0; ex < side; ex++)
             for (int ey = 0; ey < side; ey++)
                 for (int ez = 0; ez < side; ez++) {
                     int32_t val = j.root;
-                    int lvl = sh + b;
-                    for (int k = b - 1; k >= 0 && val > 0; k--) {
+                    int lvl = sh + real;
+                    if (((ex | ey | ez) >> real) != 0) val = 0;  // padding cell: air, never read
+                    for (int k = real - 1; k >= 0 && val > 0; k--) {
                         lvl--;
                         int64_t at = (int64_t)val + ((((ex >> k) & 1) << 2) | (((ey >> k) & 1) << 1) | ((ez >> k) & 1));
                         if (at < 0 || at >= n) return *why = kTree, false;

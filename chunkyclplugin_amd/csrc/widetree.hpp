@@ -42,8 +42,7 @@ bool build_wide_tree(const int32_t* oct, int64_t n_ints, int depth, const int* l
 // Sets the kind bits of every leaf from the block palette (2 ints per block: modelType, pointer).
 void annotate_wide_tree(WideTree* t, const int32_t* block_palette, int64_t n_ints);
 
-// Default split of `depth` address bits into levels: 3 bits per level from the bottom, the
-// remainder (1..3 bits) at the top.
+// Default split: ceil(depth/3) levels of 3 bits each (top level padded), see widetree.cpp.
 int default_wide_levels(int depth, int* level_bits);
 
 }  // namespace chunky
