@@ -608,12 +608,12 @@ extern "C" int chunky_render_kernel_time(chunky_render* r, float* total_ms, int*
     return CHUNKY_OK;
 }
 
-extern "C" int chunky_render_phase_stats(chunky_render* r, uint64_t* out9, int reset) {
+extern "C" int chunky_render_phase_stats(chunky_render* r, uint64_t* out12, int reset) {
     LOCK_RENDER(r);
-    if (!out9) return fail(CHUNKY_E_INVALID, "phase_stats: NULL output");
+    if (!out12) return fail(CHUNKY_E_INVALID, "phase_stats: NULL output");
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
-    HIP_TRY(hipMemcpy(out9, (char*)r->work_counter.p + 8, 72, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset((char*)r->work_counter.p + 8, 0, 72));
+    HIP_TRY(hipMemcpy(out12, (char*)r->work_counter.p + 8, 96, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset((char*)r->work_counter.p + 8, 0, 96));
     return CHUNKY_OK;
 }
 

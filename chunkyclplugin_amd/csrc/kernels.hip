@@ -50,7 +50,8 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
                 if (i == 0 || e >= 0) {
                     const int sh = 3 * (TREE - 1 - i);
                     const unsigned idx = (((unsigned)bx >> sh) & 7u) << 6 | (((unsigned)by >> sh) & 7u) << 3 | (((unsigned)bz >> sh) & 7u);
-                    e = (int)tree[(unsigned)e + idx];
+                    // byte offset in 32 bits (the builder keeps the array under 2^30 entries): SGPR base + VGPR offset
+                    e = *(const int*)((const char*)tree + (((unsigned)e + idx) << 2));
                 }
             }
         } else
@@ -283,23 +284,30 @@ DEV int trace_setup(const SceneView& S, LaneState& L) {
     return ST_MARCH;
 }
 
+// Written without early returns: the arithmetic runs for every lane of the phase (it is harmless for
+// a lane whose trace has ended), only the tree reads are guarded, and the outcome is three selects —
+// nested exits cost a copy of every live-out per exit in the compiled code.
 template <int TREE>
 DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     const int depth = S.octree_depth;
-    if (L.steps >= O.draw_depth || L.dist_march > L.h.distance) return ST_SHADE;
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
     int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
-    if (((bx | by | bz) >> depth) != 0) return ST_SHADE;
-    int level, data, kind;
-    leaf_lookup<TREE>(S, bx, by, bz, data, level, kind);
-    if (kind != 2) {
-        L.cand_data = data;
-        L.cand_level = level;
-        return ST_BLOCK;
-    }
-    leaf_exit<TREE>(S, L, po, bx, by, bz, level);
-    return ST_MARCH;
+    const bool live = (L.steps < O.draw_depth) & !(L.dist_march > L.h.distance) & (((bx | by | bz) >> depth) == 0);
+    int level = 0, data = 0, kind = 2;
+    if (live) leaf_lookup<TREE>(S, bx, by, bz, data, level, kind);
+    const bool cand = live & (kind != 2);
+    // leaf exit (K/octree.h:103-106) — kept only by lanes that stay in the march
+    int lx = bx >> level, ly = by >> level, lz = bz >> level;
+    const float step = box_exit((float)(lx << level), (float)((lx + 1) << level), (float)(ly << level),
+                                (float)((ly + 1) << level), (float)(lz << level), (float)((lz + 1) << level), po,
+                                L.inv) + kOffset;
+    const bool go = live & !cand;
+    L.dist_march = go ? L.dist_march + step : L.dist_march;
+    L.steps = go ? L.steps + 1 : L.steps;
+    L.cand_data = cand ? data : L.cand_data;
+    L.cand_level = cand ? level : L.cand_level;
+    return !live ? ST_SHADE : (cand ? ST_BLOCK : ST_MARCH);
 }
 
 template <int TREE>
@@ -523,6 +531,8 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
     L.gid = 0;
     L.mean = mk3(0, 0, 0);
     unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_begin = 0;
+    if (STATS) t_begin = __builtin_amdgcn_s_memtime();
     PixelPool pool{0, 0};
     int st;
     {
@@ -576,6 +586,11 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
     if (STATS && (threadIdx.x & 63) == 0) {
         unsigned long long* stats = fresh_args()->stats;
         for (int k = 0; k < 9; k++) atomicAdd(&stats[k], prof[k]);
+        // wave lifetimes: [9] sum, [10] max, [11] waves — the gap between mean and max is the launch tail
+        const unsigned long long life = __builtin_amdgcn_s_memtime() - t_begin;
+        atomicAdd(&stats[9], life);
+        atomicMax(&stats[10], life);
+        atomicAdd(&stats[11], 1ull);
     }
 }
 

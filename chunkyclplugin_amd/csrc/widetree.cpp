@@ -28,7 +28,7 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
     static const char* kBits = "level bits do not add up to the octree depth";
     static const char* kPtr = "block pointer does not fit 25 bits";
     static const char* kTree = "octree node outside the array";
-    static const char* kSize = "wide tree would exceed 2^31 entries";
+    static const char* kSize = "wide tree would exceed 2^30 entries";
     if (depth < 0 || depth > 15) return *why = kDepth, false;
     int sum = 0;
     for (int i = 0; i < nlev; i++) sum += level_bits[i];
@@ -78,7 +78,7 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
                         if (j.level + 1 >= nlev) return *why = kTree, false;  // a branch below level 0
                         const int64_t child = (int64_t)d.size();
                         const int64_t csize = (int64_t)1 << (3 * out->bits[j.level + 1]);
-                        if (child + csize >= ((int64_t)1 << 31)) return *why = kSize, false;
+                        if (child + csize >= ((int64_t)1 << 30)) return *why = kSize, false;
                         d.resize((size_t)(child + csize));
                         d[(size_t)slot] = (uint32_t)child;
                         queue.push_back(Job{child, j.level + 1, val});

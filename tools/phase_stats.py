@@ -24,9 +24,11 @@ r.render_passes(seeds[passes:], first_buffer_spp=passes)
 ms, n = r.kernel_time()
 st = r.phase_stats()
 samples = sc.width * sc.height * passes
+w = st.pop("waves")
 tot = sum(v["cycles"] for v in st.values())
 out = {"variant": variant, "launch_ms": ms / n, "Msamples/s": samples / (ms / n) / 1e3}
 for k, v in st.items():
     out[k] = {"execs_per_sample": v["execs"] * 64 / samples, "lanes_per_exec": v["lanes"] / max(v["execs"], 1),
               "cycles_per_exec": v["cycles"] / max(v["execs"], 1), "time_share": v["cycles"] / max(tot, 1)}
+out["waves"] = {"n": w["n"], "mean_life_over_max": w["life_sum"] / max(w["n"], 1) / max(w["life_max"], 1)}
 print(json.dumps(out, indent=1))
