@@ -140,8 +140,8 @@ DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O,
                    HitRecord* rec_out, int* rec_n) {
     unsigned rng = (unsigned)seed + (unsigned)gid;
     rt_pcg_next(&rng);
-    f3 o, d;
-    primary_ray(C, gid, rng, false, o, d);
+    const RayOD pr = primary_ray(C, gid, rng, false);
+    f3 o = pr.o, d = pr.d;
     f3 radiance = mk3(0, 0, 0), throughput = mk3(1, 1, 1);
     Hit h;
     h.distance = rt_inf();
@@ -495,11 +495,10 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
         // locals, not struct members, as out-parameters: keeps LaneState promotable to registers
         unsigned rng = (unsigned)A->P.seed[L.pass] + (unsigned)L.gid;  // per-lane index: a vector load from the argument segment
         rt_pcg_next(&rng);
-        f3 o, d;
-        primary_ray(C, L.gid, rng, false, o, d);
+        const RayOD pr = primary_ray(C, L.gid, rng, false);
         L.rng = rng;
-        L.o = o;
-        L.d = d;
+        L.o = pr.o;
+        L.d = pr.d;
     }
     L.radiance = mk3(0, 0, 0);
     L.throughput = mk3(1, 1, 1);
@@ -628,8 +627,8 @@ __global__ void __launch_bounds__(256) preview_lanes(SceneView S, CameraView C, 
     }
     unsigned rng = 0;
     rt_pcg_next(&rng);
-    f3 o, d;
-    primary_ray(C, gid, rng, true, o, d);
+    const RayOD pr = primary_ray(C, gid, rng, true);
+    const f3 o = pr.o, d = pr.d;
     Hit h;
     h.distance = rt_inf();
     h.material = 0;

@@ -151,6 +151,12 @@ DEV uint32_t atlas_texel(const SceneView& S, float u, float v, int location, int
     return S.atlas[((size_t)d * S.atlas_h + y) * S.atlas_w + x];
 }
 
+// (ne & 0xFF) / 255.0 evaluated in double and rounded to float (K/material.h:79) has 256 possible
+// results: a table replaces the f64 divide sequence on the hit path.
+__device__ __constant__ const float kEmittanceLut[256] = {
+#include "emit_lut.inc"
+};
+
 // K/material.h:31-82.  `shade` = false skips the writes that only matter to the main record
 // (shadow rays need the accept/reject decision only).
 DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsigned tex_size, unsigned color_w,
@@ -173,7 +179,7 @@ DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsign
     if (flags & 2)
         h.emittance = unpack_unorm8(atlas_texel(S, u, v, (int)ne, (int)tex_size)).w;
     else
-        h.emittance = (float)((double)(ne & 0xFF) / 255.0);  // double site, K/material.h:79
+        h.emittance = kEmittanceLut[ne & 0xFF];  // double site K/material.h:79, tabulated
     return true;
 }
 
@@ -494,7 +500,13 @@ DEV f3 diffuse_bounce(f3 n, unsigned& rng) {
 
 // Primary ray — K/rayTracer.cl:55-91, K/camera.h:8-32.  `unit_dir` = the preview kernel's extra
 // normalize (K/rayTracer.cl:186).
-DEV void primary_ray(const CameraView& C, int gid, unsigned& rng, bool unit_dir, f3& o, f3& d) {
+struct RayOD {
+    f3 o, d;
+};
+// Returned by value through scalars (ox..dz each assigned once per branch): out-parameters written
+// in both branches end up as a select between two addresses, which keeps them in scratch memory.
+DEV RayOD primary_ray(const CameraView& C, int gid, unsigned& rng, bool unit_dir) {
+    float ox, oy, oz, dx, dy, dz;
     if (C.projector_type != -1) {
         float x = -C.half_width + ((float)(gid % C.width) + rt_pcg_float(&rng)) * C.inv_height;
         float y = (float)(-0.5 + (double)(((float)(gid / C.width) + rt_pcg_float(&rng)) * C.inv_height));
@@ -512,13 +524,22 @@ DEV void primary_ray(const CameraView& C, int gid, unsigned& rng, bool unit_dir,
         }
         if (unit_dir) ld = normalize(ld);
         f3 m1 = mk3(C.m[0], C.m[1], C.m[2]), m2 = mk3(C.m[3], C.m[4], C.m[5]), m3 = mk3(C.m[6], C.m[7], C.m[8]);
-        d = mk3(dot(m1, ld), dot(m2, ld), dot(m3, ld));
-        o = mk3(dot(m1, lo), dot(m2, lo), dot(m3, lo)) + mk3(C.pos[0], C.pos[1], C.pos[2]);
+        dx = dot(m1, ld);
+        dy = dot(m2, ld);
+        dz = dot(m3, ld);
+        ox = dot(m1, lo) + C.pos[0];
+        oy = dot(m2, lo) + C.pos[1];
+        oz = dot(m3, lo) + C.pos[2];
     } else {
         const float* r = C.rays + (size_t)gid * 6;
-        o = mk3(r[0], r[1], r[2]);
-        d = mk3(r[3], r[4], r[5]);
+        ox = r[0];
+        oy = r[1];
+        oz = r[2];
+        dx = r[3];
+        dy = r[4];
+        dz = r[5];
     }
+    return RayOD{mk3(ox, oy, oz), mk3(dx, dy, dz)};
 }
 
 }  // namespace chunky
