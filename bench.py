@@ -82,7 +82,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from chunkyclplugin_amd import native, scenes
+    from chunkyclplugin_amd import native, parallel, scenes
     from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance
 
     torch.cuda.set_device(local_rank)
@@ -122,8 +122,7 @@ def main():
         r.render_passes(seeds[spp:spp + args.passes], first_buffer_spp=spp, sync=False)
         spp += args.passes
     r.sync()
-    if world > 1:  # the read-back collective: per-rank tiles are disjoint, zero elsewhere
-        dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+    parallel.reduce_framebuffer(fb, dst=0)  # the read-back collective (one RCCL reduce; no-op at N=1)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -141,7 +140,7 @@ def main():
         n_s, _, ctr = oracle_row_sample(sc, seeds[:1], rows, threads, count=True)
         from oracle import binding
         bytes_per_sample = binding.algorithmic_bytes(ctr)
-        local_slots = n_pix if world == 1 else (((n_pix + args.tile - 1) // args.tile + world - 1) // world) * args.tile
+        local_slots = parallel.local_slots(n_pix, 0, world, args.tile)
         passes_per_launch = min(args.passes, 64)
         launch_ms = kernel_ms / max(launches, 1)
         samples_per_launch = min(local_slots, n_pix) * passes_per_launch

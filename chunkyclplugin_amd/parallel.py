@@ -1,0 +1,43 @@
+"""Image-tile sharding across the GPUs of one node — host side.
+
+The reference is single-device; this is new.  One process per GPU (torch.distributed, backend
+"nccl" = RCCL over xGMI), the scene replicated, pixels sharded:
+
+* the pixel index range [0, W*H) is cut into tiles of `tile` consecutive gids; tile t belongs to
+  rank t % world (`chunky_render_set_shard` applies the same rule on the device: `shard_gid` in
+  csrc/kernels.hip);
+* every rank renders into a full-size framebuffer that stays zero outside its own tiles;
+* ONE collective per read-back: `reduce(SUM)` to rank 0.  Tiles are disjoint and x + 0 = x exactly,
+  so the result is bit-identical to the 1-GPU image.  Nothing is exchanged per pass.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def local_slots(n_pixels: int, rank: int, world: int, tile: int) -> int:
+    """Pixel slots (whole tiles) owned by `rank` — ShardView.n_local on the device."""
+    if world == 1:
+        return n_pixels
+    n_tiles = (n_pixels + tile - 1) // tile
+    mine = (n_tiles - rank + world - 1) // world
+    return max(mine, 0) * tile
+
+
+def owned_gids(n_pixels: int, rank: int, world: int, tile: int = 256) -> np.ndarray:
+    """Global pixel indices rendered by `rank`, in the order the device queue hands them out."""
+    slots = np.arange(local_slots(n_pixels, rank, world, tile), dtype=np.int64)
+    if world == 1:
+        return slots.astype(np.int32)
+    t, w = slots // tile, slots % tile
+    gid = (t * world + rank) * tile + w
+    return gid[gid < n_pixels].astype(np.int32)
+
+
+def reduce_framebuffer(fb, dst: int = 0):
+    """The read-back collective: sum the per-rank framebuffers (disjoint tiles, zero elsewhere)
+    onto rank `dst`.  `fb` is a torch tensor (CUDA for RCCL, CPU for gloo); returns it."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+    return fb

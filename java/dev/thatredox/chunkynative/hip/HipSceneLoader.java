@@ -1,0 +1,63 @@
+package dev.thatredox.chunkynative.hip;
+
+import dev.thatredox.chunkynative.common.export.AbstractSceneLoader;
+import dev.thatredox.chunkynative.common.export.ResourcePalette;
+import dev.thatredox.chunkynative.common.export.models.PackedAabbModel;
+import dev.thatredox.chunkynative.common.export.models.PackedBvhNode;
+import dev.thatredox.chunkynative.common.export.models.PackedQuadModel;
+import dev.thatredox.chunkynative.common.export.models.PackedTriangleModel;
+import dev.thatredox.chunkynative.common.export.primitives.PackedBlock;
+import dev.thatredox.chunkynative.common.export.primitives.PackedMaterial;
+import dev.thatredox.chunkynative.common.export.primitives.PackedSun;
+import dev.thatredox.chunkynative.common.export.texture.AbstractTextureLoader;
+import se.llbit.chunky.renderer.ResetReason;
+import se.llbit.chunky.renderer.scene.Scene;
+
+/**
+ * The ClSceneLoader of the HIP build (J/opencl/renderer/ClSceneLoader.java): same abstract hooks of
+ * AbstractSceneLoader (AbstractSceneLoader.java:184-191), but every palette ends in a
+ * chunky_scene_* call instead of a cl_mem.  The packers (PackedBlock, PackedMaterial, ...) and the
+ * whole of AbstractSceneLoader.load are reused unchanged — they define the wire formats.
+ *
+ * Blind-written (no JDK / chunky-core in the build image); see INTEGRATION.md.
+ */
+public class HipSceneLoader extends AbstractSceneLoader {
+    private final long ctx;
+    private long scene;
+
+    public HipSceneLoader(long ctx) {
+        this.ctx = ctx;
+        this.scene = HipNative.sceneCreate(ctx);
+    }
+
+    public long handle() { return scene; }
+
+    @Override
+    public boolean load(int modCount, ResetReason resetReason, Scene sceneObj) {
+        // sky bake exactly as ClSky.java:43-58, then HipNative.sceneSetSky(scene, rgba, res, res, sunIntensity)
+        HipSky.upload(scene, sceneObj);
+        return super.load(modCount, resetReason, sceneObj);
+    }
+
+    @Override
+    protected boolean loadOctree(int[] octree, int depth, int[] blockMapping, ResourcePalette<PackedBlock> blockPalette) {
+        // the remap of ClSceneLoader.java:56-58 happens natively (chunky_scene_load_octree)
+        HipNative.sceneLoadOctree(scene, octree, depth, blockMapping);
+        return true;
+    }
+
+    @Override protected AbstractTextureLoader createTextureLoader() { return new HipTextureLoader(scene); }
+    @Override protected ResourcePalette<PackedBlock> createBlockPalette() { return new HipPalette<>(scene, HipNative.PALETTE_BLOCK); }
+    @Override protected ResourcePalette<PackedMaterial> createMaterialPalette() { return new HipPalette<>(scene, HipNative.PALETTE_MATERIAL); }
+    @Override protected ResourcePalette<PackedAabbModel> createAabbModelPalette() { return new HipPalette<>(scene, HipNative.PALETTE_AABB); }
+    @Override protected ResourcePalette<PackedQuadModel> createQuadModelPalette() { return new HipPalette<>(scene, HipNative.PALETTE_QUAD); }
+    @Override protected ResourcePalette<PackedTriangleModel> createTriangleModelPalette() { return new HipPalette<>(scene, HipNative.PALETTE_TRIG); }
+
+    /** Called by AbstractSceneLoader once the BVH node arrays are packed (AbstractSceneLoader.java:118-127). */
+    protected void uploadBvh(int which, int[] packedNodes) { HipNative.sceneSetBvh(scene, which, packedNodes); }
+    protected void uploadSun(PackedSun sun) { HipNative.sceneSetSun(scene, sun.pack().toIntArray()); }
+
+    public void close() {
+        if (scene != 0) { HipNative.sceneDestroy(scene); scene = 0; }
+    }
+}

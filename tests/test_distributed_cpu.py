@@ -1,0 +1,62 @@
+"""The N>1 path on CPU: two processes over gloo.  Each rank renders only the pixels it owns (the
+oracle stands in for the device kernel here — tests may use it as the renderer of record), the
+product's sharding rule + read-back collective (chunkyclplugin_amd/parallel.py) assemble the image
+on rank 0, which must equal the single-process image bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_scenes as gs
+from chunkyclplugin_amd import parallel, scenes
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tile, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import binding
+        sc = gs.make("outdoor")
+        n = sc.width * sc.height
+        seeds = scenes.java_random_ints(3)
+        fb = np.zeros(3 * n, np.float32)
+        gids = parallel.owned_gids(n, rank, world, tile)
+        binding.port().render_gids(sc, seeds, gids, res=fb, threads=2)
+        t = torch.from_numpy(fb)
+        parallel.reduce_framebuffer(t, dst=0)
+        if rank == 0:
+            np.save(out_path, t.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tile", [256, 100])
+def test_two_ranks_reduce_to_the_single_rank_image(tmp_path, port, tile):
+    out = str(tmp_path / "fb.npy")
+    mp.spawn(_worker, args=(2, _free_port(), tile, out), nprocs=2, join=True)
+    got = np.load(out)
+    sc = gs.make("outdoor")
+    want = port.render_passes(sc, scenes.java_random_ints(3))
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,tile,n", [(1, 256, 1000), (2, 256, 3072), (3, 64, 2000), (8, 256, 1920 * 1080), (8, 100, 777)])
+def test_tiles_partition_the_image(world, tile, n):
+    seen = np.zeros(n, np.int32)
+    for r in range(world):
+        g = parallel.owned_gids(n, r, world, tile)
+        assert parallel.local_slots(n, r, world, tile) >= g.size
+        seen[g] += 1
+        if world > 1 and g.size:
+            assert ((g // tile) % world == r).all()
+    assert (seen == 1).all()
