@@ -60,9 +60,9 @@ def oracle_row_sample(sc, seeds, rows, threads, count: bool):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--passes", type=int, default=16, help="passes (spp) per step")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--passes", type=int, default=64, help="passes (spp) per step = per launch (max 64)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--chunks", type=int, default=32)
@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0, help="rig: render only rank 0's share of an N-GPU split on one GPU")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rigs")
+    ap.add_argument("--one-device", action="store_true", help="rig: every rank uses GPU 0 (1-GPU box, with --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,9 +88,14 @@ def main():
     from chunkyclplugin_amd import native, parallel, scenes
     from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance
 
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     sc = scenes.cached_outdoor_world(chunks=args.chunks, height=256, width=args.width, img_height=args.height)
     n_pix = sc.width * sc.height
@@ -97,7 +105,7 @@ def main():
     r = HipPathTracingRenderer(loader, sc.width, sc.height)
     r.set_camera(sc.projector_type, sc.camera)
     r.set_option(native.OPT_KERNEL, args.kernel)
-    r.set_shard(rank, world, args.tile)
+    r.set_shard(rank, args.emulate_world or world, args.tile)
     fb = torch.zeros(3 * n_pix, dtype=torch.float32, device="cuda")
     r.set_device_buffer(fb.data_ptr())
 
@@ -126,7 +134,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kernel_ms, launches = r.kernel_time()

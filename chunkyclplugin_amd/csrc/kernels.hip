@@ -235,12 +235,24 @@ __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, R
 // values), so the image is bit-identical; only which lanes execute together changes.  On the
 // benchmark view the one-lane-per-path form keeps 19 % of the VALU lanes busy (profiles/), because
 // a wave waits for its longest march and its deepest path.
-enum : int { ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2, ST_DONE = 3, ST_NEXT = 4, ST_SETUP = 5 };
+enum : int {
+    ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2,  // the three voted phases
+    ST_DONE = 3,   // no pixels left for this lane's group
+    ST_NEXT = 4,   // path finished, radiance ready
+    ST_SETUP = 5,  // ray ready, trace_setup pending
+    ST_HOLD = 6,   // (unused)
+    ST_IDLE = 7,   // lane is free and waits for a pass of its group's pixel
+    ST_START = 8   // begin the sample L.pass
+};
 
 struct LaneState {
     // pixel / pass
     int gid, pass;
-    f3 mean;
+    f3 mean;             // G = 1 only (grouped lanes keep the means in LDS)
+    int slot, serial;    // G > 1: which open pixel of the group this lane's pass belongs to, and its serial
+    int cur;             // G > 1, leader: the open pixel passes are issued from
+    int serial_counter;  // G > 1, leader
+    bool exhausted;      // G > 1, leader: the pixel queue is empty
     unsigned rng;
     // path
     f3 radiance, throughput, o, d;
@@ -346,6 +358,7 @@ struct PixelPool {
     int next, end;
 };
 
+template <int BATCH>
 DEV int claim_slot(WorkQueue Q, PixelPool& pool, bool need) {
     const unsigned long long mask = __ballot(need);
     if (mask == 0) return 0;
@@ -357,7 +370,7 @@ DEV int claim_slot(WorkQueue Q, PixelPool& pool, bool need) {
         pool.next += n_need;
     } else {
         // take what is left, then a fresh batch (large enough for every waiting lane)
-        const int want = n_need - rem > kPixelBatch ? n_need - rem : kPixelBatch;
+        const int want = n_need - rem > BATCH ? n_need - rem : BATCH;
         int base = 0;
         if (need && rank == 0) base = atomicAdd(Q.next, want);
         base = __builtin_amdgcn_readfirstlane(__shfl(base, __ffsll((long long)mask) - 1));
@@ -383,6 +396,7 @@ struct WaveArgs {
     WorkQueue Q;
     float* res;
     unsigned long long* stats;
+    unsigned stack_bytes;  // size of the BVH-stack area at the start of dynamic LDS
 };
 typedef const WaveArgs __attribute__((address_space(4))) * WaveArgPtr;
 
@@ -455,10 +469,11 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
     return ST_SETUP;
 }
 
-// SHADE, part 2, called from wave-uniform control flow (the pixel pool must be updated by the whole
-// wave): accumulate finished paths, hand out pixels, start the next sample of every lane in ST_NEXT.
+// SHADE, part 2 for G = 1 (one lane per pixel), called from wave-uniform control flow (the pixel
+// pool must be updated by the whole wave): accumulate finished paths, hand out pixels, start the next
+// sample of every lane in ST_NEXT.  The grouped form below does the same for G > 1.
 template <int TREE>
-DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, WaveArgPtr A, PixelPool& pool,
+DEV int next_sample_single(const SceneView& S, const CameraView& C, const ShardView& T, WaveArgPtr A, PixelPool& pool,
                     LaneState& L, int st, bool fresh) {
     const int first_spp = A->P.first_spp, n_passes = A->P.n;
     float* __restrict__ res = A->res;
@@ -480,7 +495,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
             need_pixel = true;
         }
     }
-    const int slot = claim_slot(Q, pool, need_pixel);  // convergent: every lane of the wave is here
+    const int slot = claim_slot<kPixelBatch>(Q, pool, need_pixel);  // convergent: every lane of the wave is here
     if (!nxt) return st;
     if (need_pixel) {
         int gid = slot < T.n_local ? shard_gid(T, slot) : C.width * C.height;
@@ -508,15 +523,163 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
     return ST_SETUP;
 }
 
+// SHADE, part 2 for G > 1, called from wave-uniform control flow (every lane of the wave is here: it
+// uses cross-lane operations and updates the wave's pixel pool).
+//
+// A pixel is shared by a GROUP of G adjacent lanes.  The passes of the launch are handed to the
+// group's lanes one at a time, on demand, so a work item is a single path instead of a whole pixel:
+// that removes the idle tail of the persistent grid (12 % of wave time with one lane per pixel) and
+// keeps every lane busy when a GPU owns few pixels (8-GPU strong scaling leaves one pixel per lane).
+// The running mean of K/rayTracer.cl:109-112 must still absorb the passes IN ORDER: a finished path
+// parks its radiance in the group's LDS ring at its pass index, tagged {pixel serial, pass}, and the
+// group leader folds the parked values strictly by pass index.  Same float recurrence, same order:
+// the image is bit-identical for every G.  Two pixels are open per group — passes are issued from
+// the newer one while the older one waits for its last paths — so a group never drains between pixels.
+#ifndef CHUNKY_HANDOVER_BATCH
+#define CHUNKY_HANDOVER_BATCH 4
+#endif
+constexpr int kHandoverBatch = CHUNKY_HANDOVER_BATCH;
+constexpr int kRing = 32;  // parked radiances per open pixel; a pass is issued only inside fold + kRing
+struct GroupLds {
+    float4* rad;  // [2][kRing] {r, g, b, tag}
+    int* hdr;     // [2][8]  {gid, fold, issue, serial, mean.x, mean.y, mean.z, -}
+};
+enum : int { H_GID = 0, H_FOLD = 1, H_ISSUE = 2, H_SERIAL = 3, H_MEAN = 4 };
+
+template <int TREE, int G>
+DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, WaveArgPtr A, PixelPool& pool,
+                    LaneState& L, GroupLds lds, int st) {
+    const int first_spp = A->P.first_spp, n_passes = A->P.n;
+    float* __restrict__ res = A->res;
+    WorkQueue Q = arg_copy(&A->Q);
+    const int lane = (int)(threadIdx.x & 63u);
+    const int sub = lane & (G - 1);
+    const int leader = lane & ~(G - 1);
+    const bool is_leader = sub == 0;
+    // ---- a finished path parks its radiance at its pass index ----
+    if (st == ST_NEXT) {
+        lds.rad[L.slot * kRing + (L.pass & (kRing - 1))] =
+            make_float4(L.radiance.x, L.radiance.y, L.radiance.z, __int_as_float((L.serial << 8) | L.pass));
+        st = ST_IDLE;  // free for another pass
+    }
+    // ---- leader: fold parked radiances of both open pixels, strictly in pass order ----
+    bool need_pixel = false;
+    int target = 0;
+    if (is_leader) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            int* h = lds.hdr + 8 * k;
+            const int gid = h[H_GID];
+            if (gid < 0) continue;
+            int fn = h[H_FOLD];
+            const int serial = h[H_SERIAL];
+            f3 mean = mk3(__int_as_float(h[H_MEAN]), __int_as_float(h[H_MEAN + 1]), __int_as_float(h[H_MEAN + 2]));
+            const int fn0 = fn;
+            while (fn < n_passes) {
+                const float4 c = lds.rad[k * kRing + (fn & (kRing - 1))];
+                if (__float_as_int(c.w) != ((serial << 8) | fn)) break;
+                const int spp = first_spp + fn;  // K/rayTracer.cl:109-112
+                const float fs = (float)spp, fs1 = (float)(spp + 1);
+                mean = f3{(mean.x * fs + c.x) / fs1, (mean.y * fs + c.y) / fs1, (mean.z * fs + c.z) / fs1};
+                fn++;
+            }
+            if (fn >= n_passes) {  // pixel complete
+                float* px = res + 3 * (size_t)gid;
+                px[0] = mean.x;
+                px[1] = mean.y;
+                px[2] = mean.z;
+                h[H_GID] = -1;
+            } else if (fn != fn0) {
+                h[H_FOLD] = fn;
+                h[H_MEAN] = __float_as_int(mean.x);
+                h[H_MEAN + 1] = __float_as_int(mean.y);
+                h[H_MEAN + 2] = __float_as_int(mean.z);
+            }
+        }
+        // open a new pixel when the issuing one is used up and a slot is free
+        const int cur = L.cur;
+        const bool cur_open = lds.hdr[8 * cur + H_GID] >= 0;
+        const bool cur_spent = !cur_open || lds.hdr[8 * cur + H_ISSUE] >= n_passes;
+        if (cur_spent && !L.exhausted) {
+            if (!cur_open) {
+                need_pixel = true;
+                target = cur;
+            } else if (lds.hdr[8 * (cur ^ 1) + H_GID] < 0) {
+                need_pixel = true;
+                target = cur ^ 1;
+            }
+        }
+    }
+    const int pos = claim_slot<(64 / G)>(Q, pool, need_pixel);  // small batches: pixels cannot move between waves once claimed
+    if (need_pixel) {
+        int gid = pos < T.n_local ? shard_gid(T, pos) : -1;
+        if (gid >= C.width * C.height) gid = -1;  // padding of the last tile: only padding follows
+        if (gid < 0) {
+            L.exhausted = true;
+        } else {
+            const float* px = res + 3 * (size_t)gid;
+            int* h = lds.hdr + 8 * target;
+            L.serial_counter += 1;
+            h[H_GID] = gid;
+            h[H_FOLD] = 0;
+            h[H_ISSUE] = 0;
+            h[H_SERIAL] = L.serial_counter;
+            h[H_MEAN] = __float_as_int(px[0]);
+            h[H_MEAN + 1] = __float_as_int(px[1]);
+            h[H_MEAN + 2] = __float_as_int(px[2]);
+            L.cur = target;
+        }
+    }
+    // ---- hand passes of the issuing pixel to the lanes that are free ----
+    const bool want = st == ST_IDLE;
+    const unsigned gmask = (unsigned)(__ballot(want) >> leader) & ((1u << G) - 1u);
+    const int cur = __shfl(L.cur, leader);
+    const int* h = lds.hdr + 8 * cur;
+    const int gid = h[H_GID], issue = h[H_ISSUE], serial = h[H_SERIAL];
+    int limit = h[H_FOLD] + kRing;  // ring capacity
+    limit = limit < n_passes ? limit : n_passes;
+    const int exhausted = __shfl((int)L.exhausted, leader);
+    if (want) {
+        const int p = issue + __popc(gmask & ((1u << sub) - 1u));
+        if (gid >= 0 && p < limit) {
+            L.pass = p;
+            L.slot = cur;
+            L.serial = serial;
+            L.gid = gid;
+            st = ST_START;
+        } else if (exhausted && lds.hdr[H_GID] < 0 && lds.hdr[8 + H_GID] < 0) {
+            st = ST_DONE;
+        }
+    }
+    if (is_leader && gid >= 0) {
+        int nx = issue + __popc(gmask);
+        lds.hdr[8 * cur + H_ISSUE] = nx < limit ? nx : limit;
+    }
+    if (st != ST_START) return st;
+    // ---- new sample (K/rayTracer.cl:55-91) ----
+    {
+        // locals, not struct members, as out-parameters: keeps LaneState promotable to registers
+        unsigned rng = (unsigned)A->P.seed[L.pass] + (unsigned)gid;  // per-lane index: a vector load from the argument segment
+        rt_pcg_next(&rng);
+        const RayOD pr = primary_ray(C, gid, rng, false);
+        L.rng = rng;
+        L.o = pr.o;
+        L.d = pr.d;
+    }
+    L.radiance = mk3(0, 0, 0);
+    L.throughput = mk3(1, 1, 1);
+    L.depth = 0;
+    L.shadow = false;
+    L.h.distance = rt_inf();
+    return ST_SETUP;
+}
+
 // STATS = true adds a per-phase profile of the state machine (executions, active lanes, shader
 // cycles by s_memtime), summed over waves into stats[phase*3 + {0,1,2}]; used by tools/phase_stats.py.
-template <int TREE, bool STATS>
+template <int TREE, bool STATS, int G>
 __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) {
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
-    // hot subset for MARCH (the rest of these copies is dead and never loaded)
-    const SceneView Sm = arg_copy(&fresh_args()->S);
-    const RenderOpts Om = arg_copy(&fresh_args()->O);
     LaneState L;
     L.h.material = 0;
     L.h.normal = mk3(0, 0, 0);
@@ -527,8 +690,23 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
     L.cand_data = 0;
     L.cand_level = 0;
     L.pass = 0;
-    L.gid = 0;
+    L.gid = -1;  // no pixel yet
     L.mean = mk3(0, 0, 0);
+    L.slot = 0;
+    L.serial = 0;
+    L.cur = 0;
+    L.serial_counter = 0;
+    L.exhausted = false;
+    // per-group radiance buffers behind the BVH stacks in dynamic LDS
+    GroupLds glds{nullptr};
+    if (G > 1) {
+        const unsigned stack_bytes = fresh_args()->stack_bytes;
+        char* base = (char*)lds + stack_bytes + (threadIdx.x / G) * (2 * kRing * 16 + 64);
+        glds.rad = (float4*)base;
+        glds.hdr = (int*)(base + 2 * kRing * 16);
+        for (int i = threadIdx.x & (G - 1); i < 2 * kRing; i += G) glds.rad[i] = make_float4(0, 0, 0, __int_as_float(-1));
+        for (int i = threadIdx.x & (G - 1); i < 16; i += G) glds.hdr[i] = -1;
+    }
     unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_begin = 0;
     if (STATS) t_begin = __builtin_amdgcn_s_memtime();
@@ -539,19 +717,39 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
         const SceneView S = arg_copy(&A->S);
         const CameraView C = arg_copy(&A->C);
         const ShardView T = arg_copy(&A->T);
-        st = next_sample<TREE>(S, C, T, A, pool, L, ST_NEXT, true);
+        if (G == 1)
+            st = next_sample_single<TREE>(S, C, T, A, pool, L, ST_NEXT, true);
+        else
+            st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, ST_IDLE);
         if (st == ST_SETUP) st = trace_setup(S, L);
     }
+    int idle_rounds = 0;
     for (;;) {
         const int n_march = __popcll(__ballot(st == ST_MARCH));
         const int n_block = __popcll(__ballot(st == ST_BLOCK));
         const int n_shade = __popcll(__ballot(st == ST_SHADE));
-        if ((n_march | n_block | n_shade) == 0) break;
+        if ((n_march | n_block | n_shade) == 0) {
+            // nobody is tracing: everything is parked, so folding / pixel hand-out can always advance
+            if (G == 1 || __ballot(st != ST_DONE) == 0 || ++idle_rounds > 64) break;
+            WaveArgPtr A = fresh_args();
+            const SceneView S = arg_copy(&A->S);
+            const CameraView C = arg_copy(&A->C);
+            const ShardView T = arg_copy(&A->T);
+            st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, st);
+            if (st == ST_SETUP) st = trace_setup(S, L);
+            continue;
+        }
+        idle_rounds = 0;
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         int ph;
         if (n_march >= n_block && n_march >= n_shade) {
             ph = 0;
+            // the few scalars MARCH needs are re-read here too (scalar cache hits): kept live across
+            // the whole loop they are the first thing the allocator spills to VGPR lanes
+            WaveArgPtr A = fresh_args();
+            const SceneView Sm = arg_copy(&A->S);
+            const RenderOpts Om = arg_copy(&A->O);
             if (st == ST_MARCH) st = march_phase<TREE>(Sm, Om, L);
         } else if (n_block >= n_shade) {
             ph = 1;
@@ -563,10 +761,14 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             const SceneView S = arg_copy(&A->S);
             const RenderOpts O = arg_copy(&A->O);
             if (st == ST_SHADE) st = shade_phase<TREE>(S, O, L, stack);
-            if (__ballot(st == ST_NEXT)) {
+            // G > 1: hand-over rounds cost ~300 instructions; wait until a few finished paths share one
+            if (__popcll(__ballot(st == ST_NEXT)) >= (G == 1 ? 1 : kHandoverBatch)) {
                 const CameraView C = arg_copy(&A->C);
                 const ShardView T = arg_copy(&A->T);
-                st = next_sample<TREE>(S, C, T, A, pool, L, st, false);
+                if (G == 1)
+                    st = next_sample_single<TREE>(S, C, T, A, pool, L, st, false);
+                else
+                    st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, st);
             }
             if (st == ST_SETUP) st = trace_setup(S, L);
         }
@@ -713,16 +915,39 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
                 if (S.wide_bits[i] != 3) tree = -1;
         }
         typedef void (*Kernel)(WaveArgs);
+        // lanes per pixel (see next_sample): 8, or 16 when this GPU owns few pixels (multi-GPU tile
+        // split: measured 6.9x vs 6.5x at 1/8 of a 1080p image); CHUNKY_DEBUG_GROUP=1|8|16 for experiments
+        const size_t stack = lds;
+        int group = T.n_local < (1 << 19) ? 16 : 8;
+        if (const char* g = getenv("CHUNKY_DEBUG_GROUP")) group = atoi(g);
+        if (group != 1 && group != 8 && group != 16) group = 8;
+        if (group > 1) lds += (size_t)(block / group) * (2 * kRing * 16 + 64);
         Kernel k;
-        switch (stats ? 100 + tree : tree) {
-            case 0: k = render_waves<0, false>; break;
-            case 1: k = render_waves<1, false>; break;
-            case 2: k = render_waves<2, false>; break;
-            case 3: k = render_waves<3, false>; break;
-            case 4: k = render_waves<4, false>; break;
-            case 5: k = render_waves<5, false>; break;
-            case 103: k = render_waves<3, true>; break;
-            default: k = stats ? render_waves<-1, true> : render_waves<-1, false>; break;
+        if (stats) {
+            k = tree == 3 ? (group == 1 ? render_waves<3, true, 1> : render_waves<3, true, 8>)
+                          : (group == 1 ? render_waves<-1, true, 1> : render_waves<-1, true, 8>);
+        } else if (group == 1) {
+            switch (tree) {
+                case 0: k = render_waves<0, false, 1>; break;
+                case 1: k = render_waves<1, false, 1>; break;
+                case 2: k = render_waves<2, false, 1>; break;
+                case 3: k = render_waves<3, false, 1>; break;
+                case 4: k = render_waves<4, false, 1>; break;
+                case 5: k = render_waves<5, false, 1>; break;
+                default: k = render_waves<-1, false, 1>; break;
+            }
+        } else if (group == 16) {
+            k = tree == 3 ? render_waves<3, false, 16> : render_waves<-1, false, 16>;
+        } else {
+            switch (tree) {
+                case 0: k = render_waves<0, false, 8>; break;
+                case 1: k = render_waves<1, false, 8>; break;
+                case 2: k = render_waves<2, false, 8>; break;
+                case 3: k = render_waves<3, false, 8>; break;
+                case 4: k = render_waves<4, false, 8>; break;
+                case 5: k = render_waves<5, false, 8>; break;
+                default: k = render_waves<-1, false, 8>; break;
+            }
         }
         int occ = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
@@ -734,7 +959,7 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         if (grid <= 0 || P.n <= 0) return hipSuccess;
         e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
-        WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2)};
+        WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)stack};
         hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
         return hipGetLastError();
     }

@@ -39,5 +39,10 @@ def reduce_framebuffer(fb, dst: int = 0):
     onto rank `dst`.  `fb` is a torch tensor (CUDA for RCCL, CPU for gloo); returns it."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+        if fb.is_cuda and dist.get_backend() == "gloo":  # test rigs without RCCL: stage through the host
+            host = fb.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            fb.copy_(host)
+        else:
+            dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb

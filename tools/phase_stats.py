@@ -10,12 +10,14 @@ from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, 
 
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+world = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 sc = scenes.cached_outdoor_world(chunks=32, height=256)
 loader = HipSceneLoader(RendererInstance.get(0))
 loader.load_packed(sc)
 r = HipPathTracingRenderer(loader, sc.width, sc.height)
 r.set_camera(sc.projector_type, sc.camera)
 r.set_option(native.OPT_KERNEL, variant)
+r.set_shard(0, world, 256)
 seeds = native.java_random_ints(2 * passes)
 r.render_passes(seeds[:passes])
 r.phase_stats(reset=True)
@@ -23,7 +25,7 @@ r.kernel_time()
 r.render_passes(seeds[passes:], first_buffer_spp=passes)
 ms, n = r.kernel_time()
 st = r.phase_stats()
-samples = sc.width * sc.height * passes
+samples = sc.width * sc.height * passes // world
 w = st.pop("waves")
 tot = sum(v["cycles"] for v in st.values())
 out = {"variant": variant, "launch_ms": ms / n, "Msamples/s": samples / (ms / n) / 1e3}
