@@ -612,8 +612,8 @@ extern "C" int chunky_render_phase_stats(chunky_render* r, uint64_t* out12, int 
     LOCK_RENDER(r);
     if (!out12) return fail(CHUNKY_E_INVALID, "phase_stats: NULL output");
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
-    HIP_TRY(hipMemcpy(out12, (char*)r->work_counter.p + 8, 96, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset((char*)r->work_counter.p + 8, 0, 96));
+    HIP_TRY(hipMemcpy(out12, (char*)r->work_counter.p + 8, 112, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset((char*)r->work_counter.p + 8, 0, 112));
     return CHUNKY_OK;
 }
 

@@ -708,6 +708,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
         for (int i = threadIdx.x & (G - 1); i < 16; i += G) glds.hdr[i] = -1;
     }
     unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long hand_cycles = 0, hand_execs = 0;  // the pixel/pass hand-over part of SHADE
     unsigned long long t_begin = 0;
     if (STATS) t_begin = __builtin_amdgcn_s_memtime();
     PixelPool pool{0, 0};
@@ -763,12 +764,18 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             if (st == ST_SHADE) st = shade_phase<TREE>(S, O, L, stack);
             // G > 1: hand-over rounds cost ~300 instructions; wait until a few finished paths share one
             if (__popcll(__ballot(st == ST_NEXT)) >= (G == 1 ? 1 : kHandoverBatch)) {
+                unsigned long long th = 0;
+                if (STATS) th = __builtin_amdgcn_s_memtime();
                 const CameraView C = arg_copy(&A->C);
                 const ShardView T = arg_copy(&A->T);
                 if (G == 1)
                     st = next_sample_single<TREE>(S, C, T, A, pool, L, st, false);
                 else
                     st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, st);
+                if (STATS) {
+                    hand_cycles += __builtin_amdgcn_s_memtime() - th;
+                    hand_execs += 1;
+                }
             }
             if (st == ST_SETUP) st = trace_setup(S, L);
         }
@@ -792,6 +799,8 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
         atomicAdd(&stats[9], life);
         atomicMax(&stats[10], life);
         atomicAdd(&stats[11], 1ull);
+        atomicAdd(&stats[12], hand_execs);
+        atomicAdd(&stats[13], hand_cycles);
     }
 }
 
