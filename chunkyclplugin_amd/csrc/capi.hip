@@ -85,6 +85,7 @@ struct chunky_scene {
     int sun[6] = {0, 0, 0, 0, 0, 0};
     bool have_sun = false, world_empty = true, actor_empty = true;
     bool have_world = false, have_actor = false;
+    int world_height = 0, actor_height = 0;  // inner-node levels: bounds the to-visit stack (K/bvh.h:38 uses 64)
     int refs = 1;  // owner + render targets
 };
 
@@ -282,6 +283,27 @@ extern "C" int chunky_scene_set_bvh(chunky_scene* scene, int which, const int32_
         memcpy(&f, &nodes[k], 4);
         empty = f != f;
     }
+    // height of the tree = most entries the to-visit stack can hold; also rejects child links that
+    // leave the array or form a cycle (a malformed BVH would hang the traversal)
+    int height = 0;
+    if (!empty) {
+        std::vector<std::pair<int64_t, int>> todo;
+        todo.emplace_back(0, 0);
+        int64_t visited = 0;
+        while (!todo.empty()) {
+            auto [at, d] = todo.back();
+            todo.pop_back();
+            if (at < 0 || at + 7 > n || ++visited > n) return fail(CHUNKY_E_INVALID, "set_bvh: node link outside the array or cyclic");
+            if (d > height) height = d;
+            const int32_t head = nodes[at];
+            if (head > 0) {
+                todo.emplace_back(at + 7, d + 1);
+                todo.emplace_back((int64_t)head, d + 1);
+            }
+        }
+        if (height > 63) return fail(CHUNKY_E_INVALID, "set_bvh: tree deeper than the reference's 64-entry stack");
+    }
+    (which == CHUNKY_BVH_WORLD ? scene->world_height : scene->actor_height) = height;
     DevBuf& dst = which == CHUNKY_BVH_WORLD ? scene->world_bvh : scene->actor_bvh;
     HIP_TRY(dst.upload(nodes, (size_t)n * 4, scene->ctx->stream));
     if (which == CHUNKY_BVH_WORLD) {
@@ -408,6 +430,7 @@ static int scene_view(chunky_scene* s, SceneView* v) {
         HIP_TRY(s->wide.upload(s->wide_meta.data.data(), s->wide_meta.data.size() * 4, s->ctx->stream));
         s->wide_dirty = false;
     }
+    v->bvh_stack_entries = (s->world_height > s->actor_height ? s->world_height : s->actor_height) + 1;
     v->block_info = (const int4*)s->block_info.p;
     v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;
     v->wide_nlev = s->wide_meta.nlev;

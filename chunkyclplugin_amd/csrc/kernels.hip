@@ -236,7 +236,9 @@ __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, R
 // benchmark view the one-lane-per-path form keeps 19 % of the VALU lanes busy (profiles/), because
 // a wave waits for its longest march and its deepest path.
 enum : int {
-    ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2,  // the three voted phases
+    ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2,  // voted phases (+ ST_BVH)
+    ST_BVH = 9,     // one node visit of the entity BVHs
+    ST_TRACED = 10, // octree part of the trace finished (transient)
     ST_DONE = 3,   // no pixels left for this lane's group
     ST_NEXT = 4,   // path finished, radiance ready
     ST_SETUP = 5,  // ray ready, trace_setup pending
@@ -264,7 +266,12 @@ struct LaneState {
     float dist_march;
     int steps;
     bool oct_hit;
+    bool trace_hit;  // closestIntersect result so far (octree, then the BVHs)
     int cand_data, cand_level;
+    // entity BVH traversal (K/bvh.h:22-113): current node, stack height, which BVH (0 world, 1 actor),
+    // and the shadow ray's own copy of record.distance
+    int bvh_cur, bvh_top, bvh_which;
+    float bvh_dist;
     // main record
     Hit h;
     f3 point;
@@ -280,6 +287,7 @@ DEV void leaf_exit(const SceneView& S, LaneState& L, f3 po, int bx, int by, int 
 }
 
 // Start of Octree_octreeIntersect (K/octree.h:44-64): returns the next state.
+template <int END>
 DEV int trace_setup(const SceneView& S, LaneState& L) {
     const int depth = S.octree_depth;
     L.inv = rcp3(L.d);
@@ -290,7 +298,7 @@ DEV int trace_setup(const SceneView& S, LaneState& L) {
     if ((lx != 0) | (ly != 0) | (lz != 0)) {
         float size = (float)(1 << depth);
         float dist = box_quick(0, size, 0, size, 0, size, L.o, L.inv);
-        if (dist != dist || dist < 0) return ST_SHADE;
+        if (dist != dist || dist < 0) return END;
         L.dist_march += dist + kOffset;
     }
     return ST_MARCH;
@@ -299,7 +307,7 @@ DEV int trace_setup(const SceneView& S, LaneState& L) {
 // Written without early returns: the arithmetic runs for every lane of the phase (it is harmless for
 // a lane whose trace has ended), only the tree reads are guarded, and the outcome is three selects —
 // nested exits cost a copy of every live-out per exit in the compiled code.
-template <int TREE>
+template <int TREE, int END>
 DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     const int depth = S.octree_depth;
     f3 pos = L.o + L.d * L.dist_march;
@@ -319,10 +327,10 @@ DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     L.steps = go ? L.steps + 1 : L.steps;
     L.cand_data = cand ? data : L.cand_data;
     L.cand_level = cand ? level : L.cand_level;
-    return !live ? ST_SHADE : (cand ? ST_BLOCK : ST_MARCH);
+    return !live ? END : (cand ? ST_BLOCK : ST_MARCH);
 }
 
-template <int TREE>
+template <int TREE, int END>
 DEV int block_phase(const SceneView& S, LaneState& L) {
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
@@ -340,7 +348,7 @@ DEV int block_phase(const SceneView& S, LaneState& L) {
             L.h.material = L.cand_data;
         }
         L.oct_hit = true;
-        return ST_SHADE;
+        return END;
     }
     leaf_exit<TREE>(S, L, po, bx, by, bz, L.cand_level);
     return ST_MARCH;
@@ -379,6 +387,95 @@ DEV int claim_slot(WorkQueue Q, PixelPool& pool, bool need) {
         pool.end = base + want;
     }
     return slot;
+}
+
+// The octree part of a trace is over: continue closestIntersect (K/kernel.h:16-18) in the entity BVHs.
+// A shadow trace only needs the boolean, so it skips the BVHs once anything was hit.
+DEV int bvh_begin(const SceneView& S, LaneState& L) {
+    L.trace_hit = L.oct_hit;
+    if (L.shadow && L.trace_hit) return ST_SHADE;
+    L.bvh_which = S.world_bvh_empty ? 1 : 0;
+    if (S.world_bvh_empty && S.actor_bvh_empty) return ST_SHADE;
+    L.bvh_cur = 0;
+    L.bvh_top = 0;
+    L.bvh_dist = L.h.distance;
+    return ST_BVH;
+}
+
+// BVH phase: ONE node visit of Bvh_intersect (K/bvh.h:47-109) — a leaf's triangles, or the two box
+// tests of an inner node with the near-first / push-far ordering.  The to-visit stack lives in LDS.
+DEV int bvh_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
+    const int* __restrict__ bvh = L.bvh_which ? S.actor_bvh : S.world_bvh;
+    const int* __restrict__ trigs = S.trigs;
+    float limit = L.shadow ? L.bvh_dist : L.h.distance;
+    bool finished = false;
+    const int head = bvh[L.bvh_cur];
+    if (head <= 0) {
+        const int prim = -head;
+        const int n = trigs[prim];
+        for (int i = 0; i < n; i++) {
+            f3 nn;
+            float u, v;
+            int mat;
+            float dist = triangle_hit(trigs + prim + 1 + 20 * i, limit, L.o, L.d, nn, u, v, mat);
+            if (dist == dist) {
+                Hit t = L.h;
+                if (material_sample(S, mat, u, v, t)) {
+                    if (!L.shadow) {
+                        L.h.color = t.color;
+                        L.h.emittance = t.emittance;
+                        L.h.normal = nn;
+                        L.h.distance = dist;
+                    }
+                    limit = dist;
+                    L.trace_hit = true;
+                }
+            }
+        }
+        if (L.shadow) L.bvh_dist = limit;
+        if ((L.shadow && L.trace_hit) || L.bvh_top == 0)
+            finished = true;
+        else
+            L.bvh_cur = stack.pop(--L.bvh_top);
+    } else {
+        const int second = head;
+        const int* a = bvh + L.bvh_cur + 7;
+        const int* b = bvh + second;
+        float t1 = box_quick(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
+                             as_float(a[6]), L.o, L.inv);
+        float t2 = box_quick(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
+                             as_float(b[6]), L.o, L.inv);
+        const bool miss1 = (t1 != t1) || t1 > limit;
+        const bool miss2 = (t2 != t2) || t2 > limit;
+        if (miss1) {
+            if (miss2) {
+                if (L.bvh_top == 0)
+                    finished = true;
+                else
+                    L.bvh_cur = stack.pop(--L.bvh_top);
+            } else {
+                L.bvh_cur = second;
+            }
+        } else if (miss2) {
+            L.bvh_cur += 7;
+        } else if (t1 < t2) {
+            stack.push(L.bvh_top++, second);
+            L.bvh_cur += 7;
+        } else {
+            stack.push(L.bvh_top++, L.bvh_cur + 7);
+            L.bvh_cur = second;
+        }
+    }
+    if (finished) {
+        if (L.bvh_which == 0 && !S.actor_bvh_empty && !(L.shadow && L.trace_hit)) {
+            L.bvh_which = 1;
+            L.bvh_cur = 0;
+            L.bvh_top = 0;
+            return ST_BVH;
+        }
+        return ST_SHADE;
+    }
+    return ST_BVH;
 }
 
 // All launch parameters travel as ONE by-value struct and are read through the kernel-argument
@@ -420,18 +517,9 @@ DEV WaveArgPtr fresh_args() {
 
 // SHADE, part 1: everything from the end of a trace to the start of the next one on the same path.
 // Returns ST_SETUP (a ray is ready to be traced) or ST_NEXT (the path is finished).
-template <int TREE>
+template <int TREE, bool BVH>
 DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsStack& stack) {
-    // ---- finish closestIntersect (K/kernel.h:14-24) ----
-    bool hit = L.oct_hit;
-    if (!L.shadow) {
-        if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, L.o, L.d, L.h, stack);
-        if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, L.o, L.d, L.h, stack);
-    } else if (!hit && (!S.world_bvh_empty || !S.actor_bvh_empty)) {
-        Hit sh = L.h;
-        if (!S.world_bvh_empty) hit |= bvh_hit(S, S.world_bvh, L.o, L.d, sh, stack);
-        if (!S.actor_bvh_empty) hit |= bvh_hit(S, S.actor_bvh, L.o, L.d, sh, stack);
-    }
+    const bool hit = BVH ? L.trace_hit : L.oct_hit;  // closestIntersect (K/kernel.h:14-24) is complete
     // Each block below appears once, so a shade round issues it once however the lanes split.
     const bool main_trace = !L.shadow;
     if (!hit) {  // intersectSky (K/kernel.h:26-31); record.emittance = 1 for the main ray (K/rayTracer.cl:95)
@@ -676,8 +764,10 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
 
 // STATS = true adds a per-phase profile of the state machine (executions, active lanes, shader
 // cycles by s_memtime), summed over waves into stats[phase*3 + {0,1,2}]; used by tools/phase_stats.py.
-template <int TREE, bool STATS, int G>
+// BVH = false compiles the entity-BVH state out (scenes whose two BVHs are the empty sentinel).
+template <int TREE, bool STATS, int G, bool BVH = false>
 __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) {
+    constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
     LaneState L;
@@ -697,6 +787,12 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
     L.cur = 0;
     L.serial_counter = 0;
     L.exhausted = false;
+    L.steps = 0;
+    L.radiance = mk3(0, 0, 0);
+    L.oct_hit = false;
+    L.trace_hit = false;
+    L.bvh_cur = L.bvh_top = L.bvh_which = 0;
+    L.bvh_dist = 0;
     // per-group radiance buffers behind the BVH stacks in dynamic LDS
     GroupLds glds{nullptr};
     if (G > 1) {
@@ -722,14 +818,19 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             st = next_sample_single<TREE>(S, C, T, A, pool, L, ST_NEXT, true);
         else
             st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, ST_IDLE);
-        if (st == ST_SETUP) st = trace_setup(S, L);
+        if (st == ST_SETUP) st = trace_setup<END>(S, L);
     }
     int idle_rounds = 0;
     for (;;) {
+        if (BVH && __ballot(st == ST_TRACED)) {  // octree part of some traces just ended: entity BVHs next
+            const SceneView S = arg_copy(&fresh_args()->S);
+            if (st == ST_TRACED) st = bvh_begin(S, L);
+        }
         const int n_march = __popcll(__ballot(st == ST_MARCH));
         const int n_block = __popcll(__ballot(st == ST_BLOCK));
         const int n_shade = __popcll(__ballot(st == ST_SHADE));
-        if ((n_march | n_block | n_shade) == 0) {
+        const int n_bvh = BVH ? __popcll(__ballot(st == ST_BVH)) : 0;
+        if ((n_march | n_block | n_shade | n_bvh) == 0) {
             // nobody is tracing: everything is parked, so folding / pixel hand-out can always advance
             if (G == 1 || __ballot(st != ST_DONE) == 0 || ++idle_rounds > 64) break;
             WaveArgPtr A = fresh_args();
@@ -737,31 +838,35 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             const CameraView C = arg_copy(&A->C);
             const ShardView T = arg_copy(&A->T);
             st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, st);
-            if (st == ST_SETUP) st = trace_setup(S, L);
+            if (st == ST_SETUP) st = trace_setup<END>(S, L);
             continue;
         }
         idle_rounds = 0;
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         int ph;
-        if (n_march >= n_block && n_march >= n_shade) {
+        if (BVH && n_bvh > 0 && n_bvh >= n_march && n_bvh >= n_block && n_bvh >= n_shade) {
+            ph = 1;  // profiled with BLOCK
+            const SceneView S = arg_copy(&fresh_args()->S);
+            if (st == ST_BVH) st = bvh_phase(S, L, stack);
+        } else if (n_march >= n_block && n_march >= n_shade) {
             ph = 0;
             // the few scalars MARCH needs are re-read here too (scalar cache hits): kept live across
             // the whole loop they are the first thing the allocator spills to VGPR lanes
             WaveArgPtr A = fresh_args();
             const SceneView Sm = arg_copy(&A->S);
             const RenderOpts Om = arg_copy(&A->O);
-            if (st == ST_MARCH) st = march_phase<TREE>(Sm, Om, L);
+            if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
         } else if (n_block >= n_shade) {
             ph = 1;
             const SceneView S = arg_copy(&fresh_args()->S);
-            if (st == ST_BLOCK) st = block_phase<TREE>(S, L);
+            if (st == ST_BLOCK) st = block_phase<TREE, END>(S, L);
         } else {
             ph = 2;
             WaveArgPtr A = fresh_args();
             const SceneView S = arg_copy(&A->S);
             const RenderOpts O = arg_copy(&A->O);
-            if (st == ST_SHADE) st = shade_phase<TREE>(S, O, L, stack);
+            if (st == ST_SHADE) st = shade_phase<TREE, BVH>(S, O, L, stack);
             // G > 1: hand-over rounds cost ~300 instructions; wait until a few finished paths share one
             if (__popcll(__ballot(st == ST_NEXT)) >= (G == 1 ? 1 : kHandoverBatch)) {
                 unsigned long long th = 0;
@@ -777,7 +882,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
                     hand_execs += 1;
                 }
             }
-            if (st == ST_SETUP) st = trace_setup(S, L);
+            if (st == ST_SETUP) st = trace_setup<END>(S, L);
         }
         if (STATS) {
             unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
@@ -897,7 +1002,8 @@ static bool use_wide(int variant, const SceneView& S) { return S.wide != nullptr
 
 static size_t stack_lds_bytes(const SceneView& S, int block) {
     bool need = !S.world_bvh_empty || !S.actor_bvh_empty;
-    return need ? (size_t)kBvhStackEntries * block * sizeof(int) : 0;
+    int entries = S.bvh_stack_entries > 0 && S.bvh_stack_entries < kBvhStackEntries ? S.bvh_stack_entries : kBvhStackEntries;
+    return need ? (size_t)entries * block * sizeof(int) : 0;
 }
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
@@ -931,8 +1037,16 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         if (const char* g = getenv("CHUNKY_DEBUG_GROUP")) group = atoi(g);
         if (group != 1 && group != 8 && group != 16) group = 8;
         if (group > 1) lds += (size_t)(block / group) * (2 * kRing * 16 + 64);
+        const bool has_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
         Kernel k;
-        if (stats) {
+        if (has_bvh && !stats && group > 1) {
+            if (group == 16)
+                k = tree == 3 ? render_waves<3, false, 16, true> : (tree == 4 ? render_waves<4, false, 16, true> : render_waves<-1, false, 16, true>);
+            else
+                k = tree == 3 ? render_waves<3, false, 8, true> : (tree == 4 ? render_waves<4, false, 8, true> : render_waves<-1, false, 8, true>);
+        } else if (has_bvh) {
+            k = stats ? render_waves<-1, true, 1, true> : render_waves<-1, false, 1, true>;
+        } else if (stats) {
             k = tree == 3 ? (group == 1 ? render_waves<3, true, 1> : render_waves<3, true, 8>)
                           : (group == 1 ? render_waves<-1, true, 1> : render_waves<-1, true, 8>);
         } else if (group == 1) {

@@ -65,6 +65,7 @@ struct SceneView {
     f3 su, sv, sw;
     float sun_radius_cos;             // cos(0.03f), K/sky.h:73
     int world_bvh_empty, actor_bvh_empty;  // K/bvh.h:23-32 sentinel, tested at upload
+    int bvh_stack_entries;                 // height of the taller BVH + 1 (the reference reserves 64, K/bvh.h:38)
     // wide re-layout of the octree (widetree.hpp); null when it could not be built
     const uint32_t* __restrict__ wide;
     int wide_nlev;
