@@ -182,11 +182,12 @@ def main():
             # bounded CPU leg: the SAME full-resolution view, whole image, P passes with P sized from a
             # calibration run so the leg costs about --cpu-seconds of wall time on all host cores
             all_rows = sample_rows(sc.height, sc.height)
-            calib = [all_rows[(i * 131) % len(all_rows)] for i in range(64)]
-            n_c, t_c, _ = oracle_row_sample(sc, seeds[:1], calib, threads, count=False)
-            rate = n_c / max(t_c, 1e-6)
-            p_cpu = int(max(1, min(64, round(args.cpu_seconds * rate / n_pix))))
-            done, spent, _ = oracle_row_sample(sc, seeds[:p_cpu], all_rows, threads, count=False)
+            p_cpu, done, spent = 2, 0, 0.0
+            for _ in range(3):  # grow the pass count until the leg costs about --cpu-seconds
+                done, spent, _c = oracle_row_sample(sc, seeds[:p_cpu], all_rows, threads, count=False)
+                if spent >= 0.7 * args.cpu_seconds or p_cpu >= 64:
+                    break
+                p_cpu = int(min(64, max(p_cpu + 1, round(p_cpu * args.cpu_seconds / max(spent, 1e-3)))))
             out["cpu_baseline"] = {"value": round(done / spent / 1e6, 4), "unit": "Msamples/s", "cores": threads,
                                    "kind": "port",
                                    "sample": f"{done} samples = the same {sc.width}x{sc.height} view, {p_cpu} pass(es), "
