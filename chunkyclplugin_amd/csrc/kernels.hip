@@ -1035,6 +1035,12 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         const size_t stack = lds;
         int group = T.n_local < (1 << 19) ? 16 : 8;
         if (const char* g = getenv("CHUNKY_DEBUG_GROUP")) group = atoi(g);
+        switch ((variant >> 4) & 3) {  // variant bits 4-5 force the group size (tests cover all three)
+            case 1: group = 1; break;
+            case 2: group = 8; break;
+            case 3: group = 16; break;
+            default: break;
+        }
         if (group != 1 && group != 8 && group != 16) group = 8;
         if (group > 1) lds += (size_t)(block / group) * (2 * kRing * 16 + 64);
         const bool has_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;

@@ -96,7 +96,8 @@ typedef enum chunky_option {
     CHUNKY_OPT_DRAW_DEPTH = 0,      /* int, default 256  (K/rayTracer.cl:94) */
     CHUNKY_OPT_MAX_DEPTH = 1,       /* int, default 5    (K/rayTracer.cl:107) */
     CHUNKY_OPT_EMITTER_SCALE = 2,   /* float bits, default 13.0f (K/rayTracer.cl:99) */
-    CHUNKY_OPT_KERNEL = 3           /* int: kernel variant, 0 = default */
+    CHUNKY_OPT_KERNEL = 3           /* int: kernel variant, 0 = default; bit 0 reference octree layout, bit 1 one lane
+                                     * per path, bit 2 phase profile, bits 4-5 lanes per pixel 1/8/16 (all bit-identical) */
 } chunky_option;
 int chunky_render_set_option(chunky_render* r, int option, int32_t value);
 

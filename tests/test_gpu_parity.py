@@ -35,8 +35,9 @@ def assert_radiance(got, want, what):
 
 
 # CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (wide-tree lookup),
-# bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes)
-VARIANTS = [0, 1, 2, 3]
+# bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes),
+# bits 4-5 = lanes per pixel in render_waves forced to 1 / 8 / 16 (default: chosen from the shard size)
+VARIANTS = [0, 1, 2, 3, 16, 32, 48]
 
 
 def make_renderer(gpu_instance, sc, variant=0):
