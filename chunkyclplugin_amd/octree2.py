@@ -1,0 +1,263 @@
+"""Reader for Chunky scene dumps (`<scene>.octree2` + `<scene>.json`) — SURVEY.md section 8 row f1.
+
+The reference gets its octree from Chunky's `PackedOctree.treeData` in memory
+(`AbstractSceneLoader.java:148-159`, `ClSceneLoader.java:52-63`).  Without Chunky, the same tree can
+be read from the `.octree2` file Chunky writes next to a scene (format reconstructed in SURVEY.md
+Appendix D): gzip, big-endian `DataOutputStream`:
+
+    int version (6) | int paletteVersion (4) | int nBlocks | nBlocks x NBT compound payload
+    world octree:  int depth | pre-order node stream (-1 = branch followed by its 8 children in
+                   (x<<2 | y<<1 | z) order, otherwise leaf = palette index, 0x7FFFFFFE = ANY_TYPE)
+    water octree:  same (skipped) | biome textures (skipped)
+
+Block models and textures come from Chunky + Minecraft assets, which are not available, so the
+materials are procedural: every visible block becomes a full cube (model type 1) whose material is a
+flat colour derived from crc32(block name), or a hashed 16x16 texture.
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import math
+import struct
+import zlib
+from typing import List, Tuple
+
+import numpy as np
+
+from . import scenes
+
+ANY_TYPE = 0x7FFFFFFE
+
+
+class _Reader:
+    def __init__(self, data: bytes):
+        self.d, self.p = data, 0
+
+    def i8(self):
+        v = self.d[self.p]
+        self.p += 1
+        return v
+
+    def u16(self):
+        v = struct.unpack_from(">H", self.d, self.p)[0]
+        self.p += 2
+        return v
+
+    def i32(self):
+        v = struct.unpack_from(">i", self.d, self.p)[0]
+        self.p += 4
+        return v
+
+    def skip(self, n):
+        self.p += n
+
+    def string(self):
+        n = self.u16()
+        s = self.d[self.p:self.p + n].decode("utf-8", "replace")
+        self.p += n
+        return s
+
+    def payload(self, tag):
+        """NBT payload of type `tag`; returns a Python value (compounds as dicts)."""
+        if tag == 1:
+            return self.i8()
+        if tag == 2:
+            return self.u16()
+        if tag == 3:
+            return self.i32()
+        if tag == 4:
+            self.skip(8)
+            return None
+        if tag == 5:
+            self.skip(4)
+            return None
+        if tag == 6:
+            self.skip(8)
+            return None
+        if tag == 7:
+            self.skip(self.i32())
+            return None
+        if tag == 8:
+            return self.string()
+        if tag == 9:
+            t, n = self.i8(), self.i32()
+            return [self.payload(t) for _ in range(n)]
+        if tag == 10:
+            return self.compound()
+        if tag == 11:
+            self.skip(4 * self.i32())
+            return None
+        if tag == 12:
+            self.skip(8 * self.i32())
+            return None
+        raise ValueError(f"unknown NBT tag {tag} at {self.p}")
+
+    def compound(self):
+        out = {}
+        while True:
+            tag = self.i8()
+            if tag == 0:
+                return out
+            name = self.string()
+            out[name] = self.payload(tag)
+
+
+def read_octree2(path: str) -> Tuple[List[dict], int, np.ndarray]:
+    """Returns (block palette as NBT dicts, depth, pre-order node stream as int32)."""
+    r = _Reader(gzip.open(path).read())
+    version = r.i32()
+    if version not in (5, 6):
+        raise ValueError(f"unsupported .octree2 version {version}")
+    r.i32()  # palette version
+    n_blocks = r.i32()
+    palette = [r.compound() for _ in range(n_blocks)]
+    depth = r.i32()
+    # the pre-order stream ends when the root subtree is complete
+    stream = np.frombuffer(r.d, dtype=">i4", offset=r.p)
+    need, i = 1, 0
+    # walk in chunks with numpy: every -1 adds 8 pending nodes, every node consumes one
+    n = stream.size
+    pos = 0
+    CH = 1 << 20
+    while need > 0:
+        blk = stream[pos:pos + CH]
+        if blk.size == 0:
+            raise ValueError("truncated octree stream")
+        delta = np.where(blk == -1, 7, -1).astype(np.int64)
+        run = need + np.cumsum(delta)
+        done = np.nonzero(run == 0)[0]
+        if done.size:
+            pos += int(done[0]) + 1
+            need = 0
+        else:
+            need = int(run[-1])
+            pos += blk.size
+    return palette, depth, stream[:pos].astype(np.int32)
+
+
+def pack_preorder(stream: np.ndarray, n_types: int) -> np.ndarray:
+    """Pre-order node stream -> the reference's `octreeData`: index 0 = root,
+    v > 0 = index of an 8-int child group, v <= 0 = -(2 * palette index) (block pointer, each block
+    packs to 2 ints), ANY_TYPE kept.  Groups are allocated depth-first like Chunky's loader."""
+    n_branch = int((stream == -1).sum())
+    data = np.zeros(1 + 8 * n_branch, np.int64)
+    nxt = 1
+    # explicit stack of (slot to fill) in reverse child order
+    stack = [0]
+    s = stream.tolist()
+    for v in s:
+        slot = stack.pop()
+        if v == -1:
+            data[slot] = nxt
+            stack.extend(range(nxt + 7, nxt - 1, -1))
+            nxt += 8
+        elif v == ANY_TYPE or v >= n_types:
+            data[slot] = -ANY_TYPE
+        else:
+            data[slot] = -2 * v
+    assert not stack and nxt == data.size
+    return data.astype(np.int32)
+
+
+def _block_color(name: str) -> int:
+    h = zlib.crc32(name.encode())
+    r, g, b = 64 + (h & 0x7F), 64 + ((h >> 8) & 0x7F), 64 + ((h >> 16) & 0x7F)
+    # a few recognisable overrides so the city reads as a city
+    table = {"stone": (125, 125, 125), "grass_block": (110, 160, 80), "dirt": (134, 96, 67), "water": (60, 100, 200),
+             "sand": (219, 207, 163), "oak_leaves": (70, 130, 50), "glass": (200, 220, 230), "bedrock": (60, 60, 60),
+             "white_concrete": (220, 220, 220), "gray_concrete": (90, 90, 90), "black_concrete": (30, 30, 35)}
+    key = name.split(":")[-1]
+    if key in table:
+        r, g, b = table[key]
+    return 0xFF000000 | (r << 16) | (g << 8) | b
+
+
+INVISIBLE = {"minecraft:air", "minecraft:cave_air", "minecraft:void_air", "minecraft:barrier", "minecraft:structure_void"}
+
+
+def camera_from_json(cam: dict, origin=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """15 camera floats (`ClCamera.java:42-52`) from Chunky's scene JSON camera block: position minus
+    the octree origin, rotation from yaw/pitch/roll, fovTan = 2 tan(fov/2)."""
+    pos = cam["position"]
+    o = cam["orientation"]
+    yaw, pitch, roll = o["yaw"], o["pitch"], o["roll"]
+
+    def rx(a):
+        c, s = math.cos(a), math.sin(a)
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+    def ry(a):
+        c, s = math.cos(a), math.sin(a)
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+    def rz(a):
+        c, s = math.cos(a), math.sin(a)
+        return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+    # Chunky's Camera.updateTransform composes rotY(pi/2 + yaw) * rotX(pi/2 - pitch) * rotZ(roll) (pitch -pi/2 =
+    # level); chunky-core is not available to confirm, this is the combination that renders the benchmark
+    # scene upright from its saved camera
+    M = ry(math.pi / 2 + yaw) @ rx(math.pi / 2 - pitch) @ rz(roll)
+    p = np.array([pos["x"] - origin[0], pos["y"] - origin[1], pos["z"] - origin[2]])
+    fov_tan = 2.0 * math.tan(math.radians(min(max(cam.get("fov", 70.0), 0.0), 180.0)) / 2.0)
+    dof = cam.get("dof", "Infinity")
+    subject = cam.get("focalOffset", 2.0)
+    aperture = 0.0 if dof in ("Infinity", float("inf")) else subject / float(dof)
+    return np.concatenate([p, M.reshape(-1), [aperture, subject, fov_tan]]).astype(np.float32)
+
+
+def load_scene(octree2_path: str, json_path: str = None, width: int = 1920, height: int = 1080,
+               emitters: bool = False) -> scenes.PackedScene:
+    """`.octree2` (+ scene JSON for camera / sun) -> PackedScene with procedural flat-colour cubes."""
+    palette, depth, stream = read_octree2(octree2_path)
+    pal = scenes.Palettes()
+    for blk in palette:
+        name = blk.get("Name", "minecraft:air")
+        if name in INVISIBLE:
+            pal.block_invisible()
+        else:
+            emit = 1.0 if emitters and any(k in name for k in ("lantern", "glowstone", "torch", "lamp")) else 0.0
+            pal.block_cube(pal.material(argb=_block_color(name), emittance=emit))
+    tree = pack_preorder(stream, len(palette))
+    blocks, mats, aabbs, quads = pal.arrays()
+    alt, azi, inten, draw = 0.6, 1.2, 1.25, True
+    S = float(1 << depth)
+    cam = scenes.look_at_camera((0.18 * S, 0.14 * S, 0.09 * S), (0.3 * S, 0.06 * S, 0.25 * S), 70.0)
+    if json_path:
+        js = json.loads(open(json_path, encoding="latin-1").read())
+        sun = js.get("sun", {})
+        alt, azi = sun.get("altitude", alt), sun.get("azimuth", azi)
+        inten, draw = sun.get("intensity", inten), sun.get("drawTexture", draw)
+        # Chunky subtracts the octree origin from the camera (ClCamera.java:39-40): origin = min chunk * 16, yMin
+        chunks = js.get("chunkList", [])
+        if chunks:
+            ox = 16 * min(c[0] for c in chunks)
+            oz = 16 * min(c[1] for c in chunks)
+            origin = (float(ox), float(js.get("yMin", 0)), float(oz))
+            cam = camera_from_json(js["camera"], origin)
+    rng = np.random.default_rng(1)
+    ab = scenes.AtlasBuilder(2, 2)
+    tsun = ab.add(scenes.noise_texture(rng, (255, 250, 230), 4, size=32))
+    atlas, recs = ab.build()
+    return scenes.PackedScene(octree=tree, octree_depth=depth, block_palette=blocks, material_palette=mats,
+                              aabb_models=aabbs, quad_models=quads, world_bvh=scenes.empty_bvh(),
+                              actor_bvh=scenes.empty_bvh(), bvh_trigs=np.zeros(1, np.int32), atlas=atlas,
+                              sky=scenes.bake_sky(128, scenes.sun_direction(alt, azi)), sky_intensity=float(inten),
+                              sun=scenes.pack_sun(alt, azi, inten, bool(draw), recs[tsun]), camera=cam, width=width,
+                              height=height, name="octree2:" + octree2_path.split("/")[-1])
+
+
+def cached_benchmark_scene(width: int = 1920, height: int = 1080) -> scenes.PackedScene:
+    """The reference's `benchmark/OpenCL_test` scene (BASELINE.json configs[0]/[1]).  Read from
+    /root/reference where that exists and kept, as packed arrays, under .scene_cache/ so that the GPU
+    box (which has no /root/reference) gets the same input; raises FileNotFoundError when neither exists."""
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".scene_cache")
+    path = os.path.join(root, "octree2_OpenCL_test.npz")
+    src = "/root/reference/benchmark/OpenCL_test/OpenCL_test"
+    if not os.path.exists(path):
+        if not os.path.exists(src + ".octree2"):
+            raise FileNotFoundError("benchmark scene: neither " + src + ".octree2 nor " + path)
+        scenes.save_scene(load_scene(src + ".octree2", src + ".json"), path)
+    return scenes.load_scene(path).with_view(width, height)

@@ -100,3 +100,26 @@ def test_wide_tree_relayout_preserves_every_lookup():
         native.widetree_lookup(sc.octree, sc.octree_depth, xyz, [3, 2])     # bits do not sum to depth
     with pytest.raises(native.ChunkyHipError):
         native.widetree_lookup(np.array([-(1 << 28)], np.int32), 3, [[0, 0, 0]])  # pointer too large
+
+
+def test_octree2_reader_on_the_reference_benchmark_scene():
+    """`.octree2` reader: 3091 palette entries, depth 10, 345 557 branches,
+    2 764 457 packed ints; every leaf is a valid block pointer or ANY_TYPE."""
+    import os
+    import pytest
+    from chunkyclplugin_amd import octree2
+    src = "/root/reference/benchmark/OpenCL_test/OpenCL_test.octree2"
+    if not os.path.exists(src):
+        pytest.skip("reference benchmark fixture not present on this machine")
+    palette, depth, stream = octree2.read_octree2(src)
+    assert (len(palette), depth) == (3091, 10)
+    assert int((stream == -1).sum()) == 345557 and stream.size == 345557 + 2418900
+    assert palette[0]["Name"] == "minecraft:air" and palette[1]["Name"] == "minecraft:stone"
+    tree = octree2.pack_preorder(stream, len(palette))
+    assert tree.size == 2764457
+    leaves = -tree[tree <= 0].astype(np.int64)
+    ok = (leaves == scenes.ANY_TYPE) | ((leaves % 2 == 0) & (leaves < 2 * 3091))
+    assert ok.all() and int((leaves == scenes.ANY_TYPE).sum()) == 312369
+    # first leaf cell of the stream round-trips through the packed layout
+    sc = octree2.cached_benchmark_scene(64, 36)
+    assert sc.octree.size == tree.size and sc.octree_depth == 10

@@ -44,8 +44,11 @@ def run(sc, passes=32, launches=3, check_rows=(100, 500, 900)):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["indoor", "entities"]
+    which = sys.argv[1:] or ["benchmark", "indoor", "entities"]
     res = []
+    if "benchmark" in which:  # BASELINE configs[1]: the reference's own benchmark scene, 1920x1080
+        from chunkyclplugin_amd import octree2
+        res.append(run(octree2.cached_benchmark_scene(1920, 1080), passes=64, launches=3))
     if "indoor" in which:
         res.append(run(scenes.indoor_room(size=64, width=1920, img_height=1080)))
     if "entities" in which:
