@@ -14,7 +14,7 @@ from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, 
 from oracle import binding  # noqa: E402
 
 
-def run(sc, passes=32, launches=3, check_rows=(100, 500, 900)):
+def run(sc, passes=32, launches=3, check_rows=(60, 250, 440, 630, 820, 1010)):
     loader = HipSceneLoader(RendererInstance.get(0))
     loader.load_packed(sc)
     r = HipPathTracingRenderer(loader, sc.width, sc.height)
@@ -34,10 +34,17 @@ def run(sc, passes=32, launches=3, check_rows=(100, 500, 900)):
     got = r.read().reshape(sc.height, sc.width, 3)
     rows = [min(y, sc.height - 1) for y in check_rows]
     gids = np.concatenate([np.arange(y * sc.width, (y + 1) * sc.width) for y in rows]).astype(np.int32)
-    want = binding.port().render_gids(sc, seeds[:2], gids, threads=os.cpu_count()).reshape(sc.height, sc.width, 3)
+    port = binding.port()
+    port.counters(enable=True, reset=True)
+    port.counters(reset=True)
+    want = port.render_gids(sc, seeds[:2], gids, threads=os.cpu_count()).reshape(sc.height, sc.width, 3)
+    bps = binding.algorithmic_bytes(port.counters(enable=False, reset=True))
     same = all(np.array_equal(got[y].view(np.uint32), want[y].view(np.uint32)) for y in rows)
     out = {"scene": sc.name, "size": [sc.width, sc.height], "Msamples/s": sc.width * sc.height * passes * launches / dt / 1e6,
-           "launch_ms": ms / n, "rows_bit_identical_to_oracle": bool(same)}
+           "launch_ms": ms / n, "rows_bit_identical_to_oracle": bool(same),
+           "algorithmic_bytes_per_sample": bps}
+    out["algorithmic_GBps"] = bps * sc.width * sc.height * passes / (ms / n * 1e-3) / 1e9
+    out["frac_of_8TBps"] = out["algorithmic_GBps"] / 8000.0
     r.close()
     loader.close()
     return out
