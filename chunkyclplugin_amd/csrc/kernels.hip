@@ -1034,6 +1034,7 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         // split: measured 6.9x vs 6.5x at 1/8 of a 1080p image); CHUNKY_DEBUG_GROUP=1|8|16 for experiments
         const size_t stack = lds;
         int group = T.n_local < (1 << 19) ? 16 : 8;
+        if (P.n < 2 * group) group = P.n >= 16 ? 8 : 1;  // a group needs a few passes per lane to stay busy
         if (const char* g = getenv("CHUNKY_DEBUG_GROUP")) group = atoi(g);
         switch ((variant >> 4) & 3) {  // variant bits 4-5 force the group size (tests cover all three)
             case 1: group = 1; break;
