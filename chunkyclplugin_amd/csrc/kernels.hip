@@ -856,7 +856,19 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             WaveArgPtr A = fresh_args();
             const SceneView Sm = arg_copy(&A->S);
             const RenderOpts Om = arg_copy(&A->O);
-            if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
+            if (BVH || STATS) {
+                if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
+            } else {
+                // stay in the march while it keeps the majority: an inner loop whose back-edge carries
+                // only what MARCH changes (the outer loop's back-edge re-shuffles ~25 state registers)
+                int nm, nb, ns;
+                do {
+                    if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
+                    nm = __popcll(__ballot(st == ST_MARCH));
+                    nb = __popcll(__ballot(st == ST_BLOCK));
+                    ns = __popcll(__ballot(st == ST_SHADE));
+                } while (nm > 0 && nm >= nb && nm >= ns);
+            }
         } else if (n_block >= n_shade) {
             ph = 1;
             const SceneView S = arg_copy(&fresh_args()->S);
