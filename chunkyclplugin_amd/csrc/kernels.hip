@@ -235,6 +235,13 @@ __global__ void __launch_bounds__(256) render_lanes(SceneView S, CameraView C, R
 // values), so the image is bit-identical; only which lanes execute together changes.  On the
 // benchmark view the one-lane-per-path form keeps 19 % of the VALU lanes busy (profiles/), because
 // a wave waits for its longest march and its deepest path.
+// lanes of the wave for which p holds, as a 32-bit scalar (a 64-bit popcount makes the compiler do the
+// vote comparisons on the VALU: there is no 64-bit scalar less-than)
+DEV int count_lanes(bool p) {
+    const unsigned long long m = __ballot(p);
+    return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
+}
+
 enum : int {
     ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2,  // voted phases (+ ST_BVH)
     ST_BVH = 9,     // one node visit of the entity BVHs
@@ -826,9 +833,9 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_TRACED) st = bvh_begin(S, L);
         }
-        const int n_march = __popcll(__ballot(st == ST_MARCH));
-        const int n_block = __popcll(__ballot(st == ST_BLOCK));
-        const int n_shade = __popcll(__ballot(st == ST_SHADE));
+        const int n_march = count_lanes(st == ST_MARCH);
+        const int n_block = count_lanes(st == ST_BLOCK);
+        const int n_shade = count_lanes(st == ST_SHADE);
         const int n_bvh = BVH ? __popcll(__ballot(st == ST_BVH)) : 0;
         if ((n_march | n_block | n_shade | n_bvh) == 0) {
             // nobody is tracing: everything is parked, so folding / pixel hand-out can always advance
@@ -864,9 +871,9 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
                 int nm, nb, ns;
                 do {
                     if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
-                    nm = __popcll(__ballot(st == ST_MARCH));
-                    nb = __popcll(__ballot(st == ST_BLOCK));
-                    ns = __popcll(__ballot(st == ST_SHADE));
+                    nm = count_lanes(st == ST_MARCH);
+                    nb = count_lanes(st == ST_BLOCK);
+                    ns = count_lanes(st == ST_SHADE);
                 } while (nm > 0 && nm >= nb && nm >= ns);
             }
         } else if (n_block >= n_shade) {
@@ -880,7 +887,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             const RenderOpts O = arg_copy(&A->O);
             if (st == ST_SHADE) st = shade_phase<TREE, BVH>(S, O, L, stack);
             // G > 1: hand-over rounds cost ~300 instructions; wait until a few finished paths share one
-            if (__popcll(__ballot(st == ST_NEXT)) >= (G == 1 ? 1 : kHandoverBatch)) {
+            if (count_lanes(st == ST_NEXT) >= (G == 1 ? 1 : kHandoverBatch)) {
                 unsigned long long th = 0;
                 if (STATS) th = __builtin_amdgcn_s_memtime();
                 const CameraView C = arg_copy(&A->C);
