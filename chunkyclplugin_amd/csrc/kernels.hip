@@ -855,7 +855,18 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
         if (BVH && n_bvh > 0 && n_bvh >= n_march && n_bvh >= n_block && n_bvh >= n_shade) {
             ph = 1;  // profiled with BLOCK
             const SceneView S = arg_copy(&fresh_args()->S);
-            if (st == ST_BVH) st = bvh_phase(S, L, stack);
+            if (STATS) {
+                if (st == ST_BVH) st = bvh_phase(S, L, stack);
+            } else {
+                int nv, nm, nb, ns;  // keep visiting nodes while the BVH walk holds the majority
+                do {
+                    if (st == ST_BVH) st = bvh_phase(S, L, stack);
+                    nv = count_lanes(st == ST_BVH);
+                    nm = count_lanes(st == ST_MARCH);
+                    nb = count_lanes(st == ST_BLOCK);
+                    ns = count_lanes(st == ST_SHADE);
+                } while (nv > 0 && nv >= nm && nv >= nb && nv >= ns);
+            }
         } else if (n_march >= n_block && n_march >= n_shade) {
             ph = 0;
             // the few scalars MARCH needs are re-read here too (scalar cache hits): kept live across
@@ -863,8 +874,17 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             WaveArgPtr A = fresh_args();
             const SceneView Sm = arg_copy(&A->S);
             const RenderOpts Om = arg_copy(&A->O);
-            if (BVH || STATS) {
+            if (STATS) {
                 if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
+            } else if (BVH) {
+                int nm, nb, ns, nv;
+                do {
+                    if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
+                    nm = count_lanes(st == ST_MARCH);
+                    nb = count_lanes(st == ST_BLOCK);
+                    ns = count_lanes(st == ST_SHADE);
+                    nv = count_lanes(st == ST_BVH || st == ST_TRACED);
+                } while (nm > 0 && nm >= nb && nm >= ns && nm >= nv);
             } else {
                 // stay in the march while it keeps the majority: an inner loop whose back-edge carries
                 // only what MARCH changes (the outer loop's back-edge re-shuffles ~25 state registers)
