@@ -657,52 +657,48 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
             make_float4(L.radiance.x, L.radiance.y, L.radiance.z, __int_as_float((L.serial << 8) | L.pass));
         st = ST_IDLE;  // free for another pass
     }
-    // ---- leader: fold parked radiances of both open pixels, strictly in pass order ----
-    bool need_pixel = false;
-    int target = 0;
-    if (is_leader) {
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            int* h = lds.hdr + 8 * k;
-            const int gid = h[H_GID];
-            if (gid < 0) continue;
-            int fn = h[H_FOLD];
-            const int serial = h[H_SERIAL];
-            f3 mean = mk3(__int_as_float(h[H_MEAN]), __int_as_float(h[H_MEAN + 1]), __int_as_float(h[H_MEAN + 2]));
-            const int fn0 = fn;
+    // ---- fold parked radiances strictly in pass order: lane 0 of the group serves open pixel 0, lane 1
+    //      open pixel 1, so the fold code is issued once for both ----
+    int4* const hdr4 = (int4*)lds.hdr;  // per open pixel: {gid, fold, issue, serial}, {mean.x, mean.y, mean.z, -}
+    if (sub < 2) {
+        const int k = sub;
+        const int4 h = hdr4[2 * k];
+        if (h.x >= 0) {
+            const int4 m = hdr4[2 * k + 1];
+            f3 mean = mk3(__int_as_float(m.x), __int_as_float(m.y), __int_as_float(m.z));
+            int fn = h.y;
             while (fn < n_passes) {
                 const float4 c = lds.rad[k * kRing + (fn & (kRing - 1))];
-                if (__float_as_int(c.w) != ((serial << 8) | fn)) break;
+                if (__float_as_int(c.w) != ((h.w << 8) | fn)) break;
                 const int spp = first_spp + fn;  // K/rayTracer.cl:109-112
                 const float fs = (float)spp, fs1 = (float)(spp + 1);
                 mean = f3{(mean.x * fs + c.x) / fs1, (mean.y * fs + c.y) / fs1, (mean.z * fs + c.z) / fs1};
                 fn++;
             }
             if (fn >= n_passes) {  // pixel complete
-                float* px = res + 3 * (size_t)gid;
+                float* px = res + 3 * (size_t)h.x;
                 px[0] = mean.x;
                 px[1] = mean.y;
                 px[2] = mean.z;
-                h[H_GID] = -1;
-            } else if (fn != fn0) {
-                h[H_FOLD] = fn;
-                h[H_MEAN] = __float_as_int(mean.x);
-                h[H_MEAN + 1] = __float_as_int(mean.y);
-                h[H_MEAN + 2] = __float_as_int(mean.z);
+                hdr4[2 * k] = make_int4(-1, fn, h.z, h.w);
+            } else if (fn != h.y) {
+                hdr4[2 * k] = make_int4(h.x, fn, h.z, h.w);
+                hdr4[2 * k + 1] = make_int4(__float_as_int(mean.x), __float_as_int(mean.y), __float_as_int(mean.z), 0);
             }
         }
-        // open a new pixel when the issuing one is used up and a slot is free
-        const int cur = L.cur;
-        const bool cur_open = lds.hdr[8 * cur + H_GID] >= 0;
-        const bool cur_spent = !cur_open || lds.hdr[8 * cur + H_ISSUE] >= n_passes;
-        if (cur_spent && !L.exhausted) {
-            if (!cur_open) {
-                need_pixel = true;
-                target = cur;
-            } else if (lds.hdr[8 * (cur ^ 1) + H_GID] < 0) {
-                need_pixel = true;
-                target = cur ^ 1;
-            }
+    }
+    // ---- leader: open a new pixel when the issuing one is used up and a slot is free ----
+    bool need_pixel = false;
+    int target = 0;
+    if (is_leader && !L.exhausted) {
+        const int4 hc = hdr4[2 * L.cur], ho = hdr4[2 * (L.cur ^ 1)];
+        const bool cur_open = hc.x >= 0;
+        if (!cur_open) {
+            need_pixel = true;
+            target = L.cur;
+        } else if (hc.z >= n_passes && ho.x < 0) {
+            need_pixel = true;
+            target = L.cur ^ 1;
         }
     }
     const int pos = claim_slot<(64 / G)>(Q, pool, need_pixel);  // small batches: pixels cannot move between waves once claimed
@@ -713,15 +709,9 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
             L.exhausted = true;
         } else {
             const float* px = res + 3 * (size_t)gid;
-            int* h = lds.hdr + 8 * target;
             L.serial_counter += 1;
-            h[H_GID] = gid;
-            h[H_FOLD] = 0;
-            h[H_ISSUE] = 0;
-            h[H_SERIAL] = L.serial_counter;
-            h[H_MEAN] = __float_as_int(px[0]);
-            h[H_MEAN + 1] = __float_as_int(px[1]);
-            h[H_MEAN + 2] = __float_as_int(px[2]);
+            hdr4[2 * target] = make_int4(gid, 0, 0, L.serial_counter);
+            hdr4[2 * target + 1] = make_int4(__float_as_int(px[0]), __float_as_int(px[1]), __float_as_int(px[2]), 0);
             L.cur = target;
         }
     }
@@ -729,11 +719,11 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
     const bool want = st == ST_IDLE;
     const unsigned gmask = (unsigned)(__ballot(want) >> leader) & ((1u << G) - 1u);
     const int cur = __shfl(L.cur, leader);
-    const int* h = lds.hdr + 8 * cur;
-    const int gid = h[H_GID], issue = h[H_ISSUE], serial = h[H_SERIAL];
-    int limit = h[H_FOLD] + kRing;  // ring capacity
-    limit = limit < n_passes ? limit : n_passes;
     const int exhausted = __shfl((int)L.exhausted, leader);
+    const int4 hc = hdr4[2 * cur];
+    const int gid = hc.x, issue = hc.z, serial = hc.w;
+    int limit = hc.y + kRing;  // ring capacity
+    limit = limit < n_passes ? limit : n_passes;
     if (want) {
         const int p = issue + __popc(gmask & ((1u << sub) - 1u));
         if (gid >= 0 && p < limit) {
@@ -742,13 +732,13 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
             L.serial = serial;
             L.gid = gid;
             st = ST_START;
-        } else if (exhausted && lds.hdr[H_GID] < 0 && lds.hdr[8 + H_GID] < 0) {
+        } else if (exhausted && gid < 0 && hdr4[2 * (cur ^ 1)].x < 0) {
             st = ST_DONE;
         }
     }
     if (is_leader && gid >= 0) {
         int nx = issue + __popc(gmask);
-        lds.hdr[8 * cur + H_ISSUE] = nx < limit ? nx : limit;
+        hdr4[2 * cur] = make_int4(gid, hc.y, nx < limit ? nx : limit, serial);
     }
     if (st != ST_START) return st;
     // ---- new sample (K/rayTracer.cl:55-91) ----
@@ -874,9 +864,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             WaveArgPtr A = fresh_args();
             const SceneView Sm = arg_copy(&A->S);
             const RenderOpts Om = arg_copy(&A->O);
-            if (STATS) {
-                if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
-            } else if (BVH) {
+            if (BVH) {
                 int nm, nb, ns, nv;
                 do {
                     if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
@@ -888,13 +876,21 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             } else {
                 // stay in the march while it keeps the majority: an inner loop whose back-edge carries
                 // only what MARCH changes (the outer loop's back-edge re-shuffles ~25 state registers)
-                int nm, nb, ns;
+                int nm = n_march, nb, ns;
                 do {
+                    if (STATS) {  // every inner iteration counts as one MARCH execution (cycles are added below)
+                        prof[0] += 1;
+                        prof[1] += (unsigned long long)nm;
+                    }
                     if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
                     nm = count_lanes(st == ST_MARCH);
                     nb = count_lanes(st == ST_BLOCK);
                     ns = count_lanes(st == ST_SHADE);
                 } while (nm > 0 && nm >= nb && nm >= ns);
+                if (STATS) {  // undo the one execution the common accounting below adds
+                    prof[0] -= 1;
+                    prof[1] -= (unsigned long long)n_march;
+                }
             }
         } else if (n_block >= n_shade) {
             ph = 1;
