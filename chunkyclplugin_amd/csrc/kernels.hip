@@ -324,11 +324,13 @@ DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     int level = 0, data = 0, kind = 2;
     if (live) leaf_lookup<TREE>(S, bx, by, bz, data, level, kind);
     const bool cand = live & (kind != 2);
-    // leaf exit (K/octree.h:103-106) — kept only by lanes that stay in the march
-    int lx = bx >> level, ly = by >> level, lz = bz >> level;
-    const float step = box_exit((float)(lx << level), (float)((lx + 1) << level), (float)(ly << level),
-                                (float)((ly + 1) << level), (float)(lz << level), (float)((lz + 1) << level), po,
-                                L.inv) + kOffset;
+    // leaf exit (K/octree.h:103-106) — kept only by lanes that stay in the march.  The leaf box is
+    // [lv << level, (lv + 1) << level) per axis; as floats: min = float(b & -2^level) and max = min + 2^level,
+    // both exact (integers below 2^24), so this is the reference's box bit for bit.
+    const int keep = -1 << level;
+    const float size = __builtin_ldexpf(1.0f, level);
+    const float x0 = (float)(bx & keep), y0 = (float)(by & keep), z0 = (float)(bz & keep);
+    const float step = box_exit(x0, x0 + size, y0, y0 + size, z0, z0 + size, po, L.inv) + kOffset;
     const bool go = live & !cand;
     L.dist_march = go ? L.dist_march + step : L.dist_march;
     L.steps = go ? L.steps + 1 : L.steps;
