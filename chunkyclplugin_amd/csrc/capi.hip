@@ -74,8 +74,10 @@ struct DevBuf {
 
 struct chunky_scene {
     chunky_ctx* ctx = nullptr;
-    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info;
+    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, quad_aux;
     std::vector<int32_t> host_blocks, host_materials;  // kept to rebuild block_info when either changes
+    std::vector<int32_t> host_quads;                   // kept to build quad_aux
+    bool quad_aux_dirty = false;
     WideTree wide_meta;  // host copy kept so the kind bits can follow the block palette; nlev == 0 when absent
     bool wide_dirty = false;
     int octree_depth = -1;
@@ -249,6 +251,8 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
         default: return fail(CHUNKY_E_INVALID, "set_palette: unknown kind %d", kind);
     }
     HIP_TRY(dst->upload(data, (size_t)n * 4, scene->ctx->stream));
+    if (kind == CHUNKY_PALETTE_QUAD) scene->host_quads.assign(data, data + n);
+    if (kind == CHUNKY_PALETTE_QUAD || kind == CHUNKY_PALETTE_BLOCK) scene->quad_aux_dirty = true;
     if (kind == CHUNKY_PALETTE_BLOCK || kind == CHUNKY_PALETTE_MATERIAL) {
         (kind == CHUNKY_PALETTE_BLOCK ? scene->host_blocks : scene->host_materials).assign(data, data + n);
         if (kind == CHUNKY_PALETTE_BLOCK) scene->wide_dirty = true;
@@ -376,6 +380,46 @@ static float bits_to_float(int32_t i) {
     return f;
 }
 
+// quad_aux (rt_device.hpp): for every quad of every quad model the block palette points at, the
+// ray-independent values of K/primitives.h:262-276 — normalize(cross(xv, yv)), dot(n, origin), dot(xv, xv),
+// dot(yv, yv) — written at the quad's own int offset.  Same rt_math.h expressions as the kernel, so
+// the stored floats are the ones the kernel would compute.  Returns false (no table) when two
+// models overlap in a way that would make entries collide, or a pointer leaves the array.
+static bool build_quad_aux(const std::vector<int32_t>& B, const std::vector<int32_t>& Q, std::vector<float>* out) {
+    out->assign(Q.size(), 0.0f);
+    std::vector<int64_t> owner(Q.size(), -1);
+    bool any = false;
+    for (size_t k = 0; k + 1 < B.size(); k += 2) {
+        if (B[k] != 3) continue;
+        const int64_t ptr = B[k + 1];
+        if (ptr < 0 || (size_t)ptr >= Q.size()) return false;
+        const int64_t count = Q[(size_t)ptr];
+        if (count < 0 || (size_t)(ptr + 1 + 15 * count) > Q.size()) return false;
+        for (int64_t i = 0; i < count; i++) {
+            const int64_t q = ptr + 1 + 15 * i;
+            for (int w = 0; w < 6; w++) {
+                if (owner[(size_t)(q + w)] >= 0 && owner[(size_t)(q + w)] != q) return false;
+                owner[(size_t)(q + w)] = q;
+            }
+            float f[9];
+            memcpy(f, &Q[(size_t)q], sizeof f);
+            const float cx = rt_cross_c(f[4], f[8], f[5], f[7]), cy = rt_cross_c(f[5], f[6], f[3], f[8]),
+                        cz = rt_cross_c(f[3], f[7], f[4], f[6]);
+            const float rl = rt_rlen3(cx, cy, cz);
+            const float nx = cx * rl, ny = cy * rl, nz = cz * rl;
+            float* a = out->data() + q;
+            a[0] = nx;
+            a[1] = ny;
+            a[2] = nz;
+            a[3] = rt_dot3(nx, ny, nz, f[0], f[1], f[2]);
+            a[4] = rt_dot3(f[3], f[4], f[5], f[3], f[4], f[5]);
+            a[5] = rt_dot3(f[6], f[7], f[8], f[6], f[7], f[8]);
+            any = true;
+        }
+    }
+    return any;
+}
+
 // Assemble the kernel-side view; Sun_new (K/sky.h:19-40) is evaluated here, on the host, with the
 // same rt_math.h the device uses.
 static int scene_view(chunky_scene* s, SceneView* v) {
@@ -430,6 +474,14 @@ static int scene_view(chunky_scene* s, SceneView* v) {
         HIP_TRY(s->wide.upload(s->wide_meta.data.data(), s->wide_meta.data.size() * 4, s->ctx->stream));
         s->wide_dirty = false;
     }
+    if (s->quad_aux_dirty) {
+        std::vector<float> aux;
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        s->quad_aux.release();
+        if (build_quad_aux(s->host_blocks, s->host_quads, &aux)) HIP_TRY(s->quad_aux.upload(aux.data(), aux.size() * 4, s->ctx->stream));
+        s->quad_aux_dirty = false;
+    }
+    v->quad_aux = (const float*)s->quad_aux.p;
     v->bvh_stack_entries = (s->world_height > s->actor_height ? s->world_height : s->actor_height) + 1;
     v->block_info = (const int4*)s->block_info.p;
     v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;

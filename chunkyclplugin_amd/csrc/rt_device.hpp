@@ -74,6 +74,9 @@ struct SceneView {
     // full cube (K/material.h:31-40), 0} — the block-palette and material-palette reads of
     // K/block.h:36-49 as ONE 32-byte load; built at upload, null when a palette is missing
     const int4* __restrict__ block_info;
+    // per quad, at the quad's own int offset in `quads`: {normal xyz, dot(normal, origin), |xv|^2, |yv|^2} — the
+    // ray-independent part of K/primitives.h:262-276, evaluated once at upload with this same rt_math.h; null = compute
+    const float* __restrict__ quad_aux;
 };
 
 struct CameraView {
@@ -275,14 +278,27 @@ DEV float quad_model_hit(const SceneView& S, int ptr, f3 no, f3 dir, Hit& h) {
         f3 qo = mk3(as_float(q[0]), as_float(q[1]), as_float(q[2]));
         f3 xv = mk3(as_float(q[3]), as_float(q[4]), as_float(q[5]));
         f3 yv = mk3(as_float(q[6]), as_float(q[7]), as_float(q[8]));
-        f3 n = normalize(cross(xv, yv));
+        f3 n;
+        float n_qo, xx, yy;
+        if (S.quad_aux) {
+            const float* a = S.quad_aux + (q - S.quads);
+            n = mk3(a[0], a[1], a[2]);
+            n_qo = a[3];
+            xx = a[4];
+            yy = a[5];
+        } else {
+            n = normalize(cross(xv, yv));
+            n_qo = dot(n, qo);
+            xx = dot(xv, xv);
+            yy = dot(yv, yv);
+        }
         float denom = dot(dir, n);
         if (!(denom < -kEps)) continue;
-        float t = -(dot(no, n) - dot(n, qo)) / denom;
+        float t = -(dot(no, n) - n_qo) / denom;
         if (!(t > -kEps && t < best)) continue;
         f3 pt = (no + dir * t) - qo;
-        float u = dot(pt, xv) / dot(xv, xv);
-        float v = dot(pt, yv) / dot(yv, yv);
+        float u = dot(pt, xv) / xx;
+        float v = dot(pt, yv) / yy;
         if (!(u >= 0 && u <= 1 && v >= 0 && v <= 1)) continue;
         float tu = as_float(q[9]) + (u * as_float(q[10]));
         float tv = as_float(q[11]) + (v * as_float(q[12]));
