@@ -840,6 +840,52 @@ extern "C" int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int d
     return CHUNKY_OK;
 }
 
+// ------------------------------------------------------------------------------------ tone map
+extern "C" int chunky_filter_frame(chunky_ctx* ctx, int width, int height, double exposure, const double* input,
+                                   int32_t* argb_out, int type) {
+    if (!ctx) return fail(CHUNKY_E_INVALID, "filter_frame: NULL context");
+    if (width < 0 || height < 0) return fail(CHUNKY_E_INVALID, "filter_frame: %dx%d", width, height);
+    const long long n = (long long)width * height;
+    if (n == 0) return CHUNKY_OK;
+    if (!input || !argb_out) return fail(CHUNKY_E_INVALID, "filter_frame: NULL buffer");
+    std::lock_guard<std::recursive_mutex> guard(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf in, out;
+    HIP_TRY(in.upload(input, (size_t)n * 24, ctx->stream));
+    HIP_TRY(hipMalloc(&out.p, (size_t)n * 4));
+    out.bytes = (size_t)n * 4;
+    HIP_TRY(launch_filter(n, (float)exposure, (const double*)in.p, (unsigned*)out.p, type, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(argb_out, out.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_filter_frame_device(chunky_ctx* ctx, int64_t n_pixels, float exposure, const void* d_input,
+                                          void* d_argb, int type, int repeat, float* kernel_ms) {
+    if (!ctx) return fail(CHUNKY_E_INVALID, "filter_frame_device: NULL context");
+    if (n_pixels < 0 || repeat < 1) return fail(CHUNKY_E_INVALID, "filter_frame_device: n_pixels=%lld repeat=%d", (long long)n_pixels, repeat);
+    if (n_pixels > 0 && (!d_input || !d_argb)) return fail(CHUNKY_E_INVALID, "filter_frame_device: NULL buffer");
+    if ((reinterpret_cast<uintptr_t>(d_input) & 7u) || (reinterpret_cast<uintptr_t>(d_argb) & 3u))
+        return fail(CHUNKY_E_INVALID, "filter_frame_device: misaligned buffer");
+    std::lock_guard<std::recursive_mutex> guard(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipError_t err = hipEventRecord(e0, ctx->stream);
+    for (int k = 0; k < repeat && err == hipSuccess; k++)
+        err = launch_filter(n_pixels, exposure, (const double*)d_input, (unsigned*)d_argb, type, ctx->stream);
+    if (err == hipSuccess) err = hipEventRecord(e1, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    float ms = 0;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(CHUNKY_E_HIP, "filter_frame_device: %s", hipGetErrorString(err));
+    if (kernel_ms) *kernel_ms = ms / (float)repeat;
+    return CHUNKY_OK;
+}
+
 // ------------------------------------------------------------------------------------ self test
 extern "C" int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const float* a, const float* b, float* out) {
     if (!ctx) return fail(CHUNKY_E_INVALID, "NULL context");

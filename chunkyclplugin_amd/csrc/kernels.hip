@@ -1027,9 +1027,86 @@ __global__ void math_selftest_kernel(int which, int n, const float* __restrict__
         case 13: r = (float)(int)x; break;
         case 14: r = (float)((double)((unsigned)(int)x & 0xFF) / 255.0); break;
         case 15: r = (float)(-0.5 + (double)(x * y)); break;
+        case 16: r = rt_pow(x, y); break;
+        case 17: r = (float)((double)x * (double)y); break;
         default: break;
     }
     out[i] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// `filter` — tonemap/include/post_processing_filter.cl:5-51: 3 doubles per pixel in, one ARGB word
+// out; 28 bytes of HBM traffic per pixel and nothing to reuse, so the kernel is a streaming copy
+// with arithmetic in the shadow of the loads.  A workgroup takes 512 pixels = 1536 doubles at a
+// time: every lane reads three consecutive 16-byte pairs of the tile (fully coalesced), the pairs are
+// narrowed to float (double.h:19-21, fp64 present) into LDS, and each lane then picks up the three
+// channels of its two pixels (stride-3 LDS reads, conflict-free).
+constexpr int kFilterTile = 512;
+
+DEV unsigned filter_to_uint(float f) {  // (uint) of color_to_argb (rgba.h:9-14); saturating outside the uint range
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (unsigned)f;
+}
+
+DEV float filter_channel(float c, int type) {
+    switch (type) {
+        case 0:  // GAMMA
+            return rt_pow(c, (float)(1.0 / 2.2));
+        case 1:  // TONEMAP1
+            c = rt_fmax(0.0f, c - 0.004f);
+            return (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
+        case 2:  // ACES
+            c = (c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f);
+            c = rt_clamp(c, 0.0f, 1.0f);
+            return rt_pow(c, (float)(1.0 / 2.2));
+        case 3: {  // HABLE
+            c *= 16.0f;
+            c = ((c * (0.15f * c + 0.10f * 0.50f) + 0.20f * 0.02f) / (c * (0.15f * c + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f;
+            const float white = ((11.2f * (0.15f * 11.2f + 0.10f * 0.50f) + 0.20f * 0.02f) / (11.2f * (0.15f * 11.2f + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f;
+            return c / white;
+        }
+        default: return c;  // the reference's switch has no default: exposure only
+    }
+}
+
+DEV unsigned filter_pixel(float r, float g, float b, float exposure, int type) {
+    r = filter_channel(r * exposure, type);
+    g = filter_channel(g * exposure, type);
+    b = filter_channel(b * exposure, type);
+    unsigned ur = filter_to_uint(r * 255.0f + 0.5f), ug = filter_to_uint(g * 255.0f + 0.5f), ub = filter_to_uint(b * 255.0f + 0.5f);
+    ur = ur > 255u ? 255u : ur;
+    ug = ug > 255u ? 255u : ug;
+    ub = ub > 255u ? 255u : ub;
+    return 0xFF000000u | (ur << 16) | (ug << 8) | ub;  // alpha: (uint)(1 * 255 + 0.5) = 255
+}
+
+__global__ __launch_bounds__(256) void filter_kernel(long long n, float exposure, const double* __restrict__ in,
+                                                     unsigned* __restrict__ out, int type, int vec_ok) {
+    __shared__ float stage[3 * kFilterTile];
+    const int t = threadIdx.x;
+    const long long total = 3 * n;
+    for (long long base = (long long)blockIdx.x * kFilterTile; base < n; base += (long long)gridDim.x * kFilterTile) {
+        const long long first = 3 * base;
+        if (vec_ok && base + kFilterTile <= n) {
+            const double2* __restrict__ src = reinterpret_cast<const double2*>(in + first);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double2 v = src[t + 256 * k];
+                stage[2 * (t + 256 * k)] = (float)v.x;
+                stage[2 * (t + 256 * k) + 1] = (float)v.y;
+            }
+        } else {
+            for (int k = t; k < 3 * kFilterTile; k += 256) stage[k] = first + k < total ? (float)in[first + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int px = t + 256 * k;
+            if (base + px < n) out[base + px] = filter_pixel(stage[3 * px], stage[3 * px + 1], stage[3 * px + 2], exposure, type);
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------ launchers
@@ -1168,6 +1245,15 @@ hipError_t launch_preview(int variant, const SceneView& S, const CameraView& C, 
 
 hipError_t launch_math_selftest(int which, int n, const float* a, const float* b, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(math_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, which, n, a, b, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter(long long n_pixels, float exposure, const double* in, unsigned* out, int type, hipStream_t stream) {
+    if (n_pixels <= 0) return hipSuccess;
+    long long tiles = (n_pixels + kFilterTile - 1) / kFilterTile;
+    int blocks = (int)(tiles < 4096 ? tiles : 4096);
+    int vec_ok = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    hipLaunchKernelGGL(filter_kernel, dim3(blocks), dim3(256), 0, stream, n_pixels, exposure, in, out, type, vec_ok);
     return hipGetLastError();
 }
 

@@ -212,6 +212,78 @@ RT_FN void rt_mirror_linear(float s, int w, int* i0, int* i1, float* a) {
     *i1 = j1 > w - 1 ? w - 1 : j1;
 }
 
+/* ---- pow (the tone-map kernel, reference tonemap/include/post_processing_filter.cl:24-44) --------
+ * OpenCL bounds pow at 16 ULP; this definition is x^y = 2^(y*log2|x|) evaluated in binary64 from
+ * + - * / fma only and rounded once to binary32 (about 0.5 ULP), with C99's special cases.  binary64
+ * arithmetic is IEEE-exact on x86-64 and gfx950 alike, so host and device agree bit for bit. */
+RT_FN unsigned long long rt_d2u(double d) { unsigned long long u; __builtin_memcpy(&u, &d, 8); return u; }
+RT_FN double rt_u2d(unsigned long long u) { double d; __builtin_memcpy(&d, &u, 8); return d; }
+/* log2 of a positive, finite, normal double */
+RT_FN double rt_log2_d(double x) {
+    const unsigned long long u = rt_d2u(x);
+    int e = (int)((u >> 52) & 0x7ffu) - 1023;
+    double m = rt_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1, 2) */
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    /* ln m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716: odd series to s^21 (next term < 2e-18) */
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, z, 1.0 / 19.0);
+    p = __builtin_fma(p, z, 1.0 / 17.0);
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    p = __builtin_fma(p, z, 1.0);
+    return __builtin_fma((2.0 * s) * p, 1.4426950408889634 /* 1/ln 2 */, (double)e);
+}
+/* 2^t for |t| <= 200 */
+RT_FN double rt_exp2_d(double t) {
+    const double n = __builtin_rint(t);
+    const double f = (t - n) * 0.6931471805599453; /* |f| <= 0.3466; Taylor to f^13 (next term < 5e-18) */
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, f, 1.0 / 479001600.0);
+    p = __builtin_fma(p, f, 1.0 / 39916800.0);
+    p = __builtin_fma(p, f, 1.0 / 3628800.0);
+    p = __builtin_fma(p, f, 1.0 / 362880.0);
+    p = __builtin_fma(p, f, 1.0 / 40320.0);
+    p = __builtin_fma(p, f, 1.0 / 5040.0);
+    p = __builtin_fma(p, f, 1.0 / 720.0);
+    p = __builtin_fma(p, f, 1.0 / 120.0);
+    p = __builtin_fma(p, f, 1.0 / 24.0);
+    p = __builtin_fma(p, f, 1.0 / 6.0);
+    p = __builtin_fma(p, f, 0.5);
+    p = __builtin_fma(p, f, 1.0);
+    p = __builtin_fma(p, f, 1.0);
+    return p * rt_u2d((unsigned long long)((int)n + 1023) << 52);
+}
+RT_FN float rt_pow(float x, float y) {
+    if (y == 0.0f || x == 1.0f) return 1.0f;
+    if (x != x || y != y) return rt_nan();
+    const float ax = rt_fabs(x), ay = rt_fabs(y);
+    if (ay == rt_inf()) {
+        if (ax == 1.0f) return 1.0f;
+        return ((ax < 1.0f) == (y < 0.0f)) ? rt_inf() : 0.0f;
+    }
+    const int y_int = rt_trunc(y) == y;
+    const int y_odd = y_int && ay < 16777216.0f && (((int)ay) & 1);
+    const int neg = (int)(rt_f2u(x) >> 31);
+    if (ax == 0.0f || ax == rt_inf()) {
+        const float r = ((ax == 0.0f) == (y < 0.0f)) ? rt_inf() : 0.0f;
+        return (neg && y_odd) ? -r : r;
+    }
+    if (neg && !y_int) return rt_nan();
+    double t = (double)y * rt_log2_d((double)ax);
+    t = t > 200.0 ? 200.0 : (t < -200.0 ? -200.0 : t);
+    const float r = (float)rt_exp2_d(t);
+    return (neg && y_odd) ? -r : r;
+}
+
 /* PCG hash (reference randomness.h:6-11) — 32-bit wraparound arithmetic. */
 RT_FN unsigned rt_pcg_next(unsigned* state) {
     unsigned s = *state * 47796405u + 2891336453u;

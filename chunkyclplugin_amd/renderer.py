@@ -220,3 +220,47 @@ class HipPathTracingRenderer:
         if self._h:
             check(native.lib().chunky_render_destroy(self._h))
             self._h = C.c_void_p()
+
+
+class HipPostProcessingFilter:
+    """GPU tone mapping — GpuPostProcessingFilter / ImposterCombinationGpuPostProcessingFilter
+    (tonemap/GpuPostProcessingFilter.java:14-82): takes the name, description and id of the Chunky
+    filter it stands in for (ChunkyCl.java:60-63: GAMMA, TONEMAP1, TONEMAP2 = ACES, TONEMAP3 = HABLE)
+    and runs the `filter` kernel (tonemap/include/post_processing_filter.cl:5-51) in process_frame."""
+
+    GAMMA, TONEMAP1, ACES, HABLE = 0, 1, 2, 3
+    IMPOSTERS = {"GAMMA": GAMMA, "TONEMAP1": TONEMAP1, "TONEMAP2": ACES, "TONEMAP3": HABLE}
+
+    def __init__(self, filter_id: str, instance: Optional[RendererInstance] = None, name: str = None, description: str = None):
+        if filter_id not in self.IMPOSTERS:
+            raise ValueError(f"no GPU filter for post-processing id {filter_id!r}")
+        self.instance = instance or RendererInstance.get()
+        self.id, self.type = filter_id, self.IMPOSTERS[filter_id]
+        self.name = name or filter_id
+        self.description = description or filter_id
+
+    def get_id(self) -> str:
+        return self.id
+
+    def get_name(self) -> str:
+        return self.name
+
+    def get_description(self) -> str:
+        return self.description
+
+    def process_frame(self, width: int, height: int, input_samples: np.ndarray, output_argb: np.ndarray, exposure: float) -> None:
+        """processFrame (GpuPostProcessingFilter.java:40-65): `input_samples` = width*height*3 doubles, `output_argb` =
+        width*height int32 (BitmapImage.data); blocking."""
+        if input_samples.dtype != np.float64 or input_samples.size != 3 * width * height or not input_samples.flags.c_contiguous:
+            raise ValueError("input must be a contiguous float64 array of width*height*3 samples")
+        if output_argb.dtype not in (np.int32, np.uint32) or output_argb.size != width * height or not output_argb.flags.c_contiguous:
+            raise ValueError("output must be a contiguous int32 array of width*height pixels")
+        check(native.lib().chunky_filter_frame(self.instance._h, width, height, float(exposure), ptr(input_samples),
+                                               ptr(output_argb), self.type))
+
+    def process_device(self, n_pixels: int, exposure: float, d_input: int, d_argb: int, repeat: int = 1) -> float:
+        """The same kernel on device buffers; returns the mean kernel time in ms (HIP events)."""
+        ms = C.c_float()
+        check(native.lib().chunky_filter_frame_device(self.instance._h, n_pixels, float(np.float32(exposure)), C.c_void_p(d_input),
+                                                      C.c_void_p(d_argb), self.type, repeat, C.byref(ms)))
+        return ms.value

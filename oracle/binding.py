@@ -97,6 +97,12 @@ class _Lib:
         f = getattr(self.lib, p + "_math")
         f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         f.restype = None
+        f = getattr(self.lib, p + "_filter")
+        f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+        f.restype = None
+        f = getattr(self.lib, p + "_pow")
+        f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = None
 
     def render_passes(self, sc, seeds, first_spp: int = 0, res: Optional[np.ndarray] = None,
                       gid_range=None, threads: int = 8) -> np.ndarray:
@@ -124,6 +130,22 @@ class _Lib:
         n = getattr(self.lib, self.prefix + "_trace_records")(
             C.byref(h.struct), int(seed), int(gid), _ptr(hits), _ptr(rad))
         return hits[:n], rad
+
+    def filter(self, samples, exposure: float, type_: int, width: int = 0, height: int = 0) -> np.ndarray:
+        """The tone-map kernel on `samples` (3 doubles per pixel): one ARGB word per pixel."""
+        samples = np.ascontiguousarray(samples, np.float64).reshape(-1)
+        n = samples.size // 3
+        out = np.zeros(n, np.uint32)
+        getattr(self.lib, self.prefix + "_filter")(n, width or n, height or 1, float(np.float32(exposure)), _ptr(samples),
+                                                   _ptr(out), int(type_))
+        return out
+
+    def pow(self, a, b) -> np.ndarray:
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        out = np.empty_like(a)
+        getattr(self.lib, self.prefix + "_pow")(a.size, _ptr(a), _ptr(b), _ptr(out))
+        return out
 
     def math(self, which: int, a, b=None) -> np.ndarray:
         a = np.ascontiguousarray(a, np.float32)

@@ -795,3 +795,52 @@ void port_math(int which, int n, const float* a, const float* b, float* out) {
         }
     }
 }
+
+/* ------------------------------------------------------------------------------ tone map ----
+ * `filter`, tonemap/include/post_processing_filter.cl:5-51, with fp64 present (double.h:19-21):
+ * per channel c = (float)input * exposure, then the curve selected by `type`, then color_to_argb
+ * (rgba.h:6-17).  The (uint) conversion of rgba.h:9-14 is undefined for NaN / negative / >= 2^32 in
+ * OpenCL; this restatement (and the HIP kernel) saturates there. */
+static uint32_t filter_to_uint(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+static float filter_channel(float c, int type) {
+    switch (type) {
+        case 0: /* :24-27 */
+            return rt_pow(c, (float)(1.0 / 2.2));
+        case 1: /* :28-32 */
+            c = rt_fmax(0.0f, c - 0.004f);
+            return (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
+        case 2: /* :33-38 */
+            c = (c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f);
+            c = rt_clamp(c, 0.0f, 1.0f);
+            return rt_pow(c, (float)(1.0 / 2.2));
+        case 3: { /* :39-44 */
+            c *= 16;
+            c = ((c * (0.15f * c + 0.10f * 0.50f) + 0.20f * 0.02f) / (c * (0.15f * c + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f;
+            c /= (((11.2f * (0.15f * 11.2f + 0.10f * 0.50f) + 0.20f * 0.02f) / (11.2f * (0.15f * 11.2f + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f);
+            return c;
+        }
+        default: return c;
+    }
+}
+void port_filter(int n, int width, int height, float exposure, const uint64_t* input, uint32_t* res, int type) {
+    (void)width;
+    (void)height;
+    for (int gid = 0; gid < n; gid++) {
+        uint32_t ch[3];
+        for (int i = 0; i < 3; i++) {
+            double d;
+            memcpy(&d, &input[3 * (size_t)gid + i], 8);
+            float c = filter_channel((float)d * exposure, type);
+            uint32_t u = filter_to_uint(c * 255.0f + 0.5f);
+            ch[i] = u > 255u ? 255u : u;
+        }
+        res[gid] = (255u << 24) | (ch[0] << 16) | (ch[1] << 8) | ch[2];
+    }
+}
+void port_pow(int n, const float* a, const float* b, float* out) {
+    for (int i = 0; i < n; i++) out[i] = rt_pow(a[i], b[i]);
+}

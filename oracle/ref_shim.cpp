@@ -118,6 +118,23 @@ void ocl_vstore3(cl_float3 v, size_t off, float* p) {
     p[3 * off + 2] = v.z;
 }
 
+/* ---- builtins used only by the tone-map kernel (tonemap/include/post_processing_filter.cl) ---- */
+typedef unsigned cl_uint4 __attribute__((ext_vector_type(4)));
+cl_float3 ocl_pow3(cl_float3 a, cl_float3 b) OCL("_Z3powDv3_fS_");
+cl_float3 ocl_pow3(cl_float3 a, cl_float3 b) { return (cl_float3){rt_pow(a.x, b.x), rt_pow(a.y, b.y), rt_pow(a.z, b.z)}; }
+cl_float3 ocl_clamp3v(cl_float3 v, cl_float3 lo, cl_float3 hi) OCL("_Z5clampDv3_fS_S_");
+cl_float3 ocl_clamp3v(cl_float3 v, cl_float3 lo, cl_float3 hi) {
+    return (cl_float3){rt_clamp(v.x, lo.x, hi.x), rt_clamp(v.y, lo.y, hi.y), rt_clamp(v.z, lo.z, hi.z)};
+}
+cl_uint4 ocl_clampu4(cl_uint4 v, cl_uint4 lo, cl_uint4 hi) OCL("_Z5clampDv4_jS_S_");
+cl_uint4 ocl_clampu4(cl_uint4 v, cl_uint4 lo, cl_uint4 hi) {
+    cl_uint4 r;
+    for (int i = 0; i < 4; i++) r[i] = v[i] < lo[i] ? lo[i] : (v[i] > hi[i] ? hi[i] : v[i]);
+    return r;
+}
+cl_float3 ocl_vload3p(size_t off, const float* p) OCL("_Z6vload3mPU9CLprivateKf");
+cl_float3 ocl_vload3p(size_t off, const float* p) { return (cl_float3){p[3 * off], p[3 * off + 1], p[3 * off + 2]}; }
+
 /* atlas: CLK_NORMALIZED_COORDS_FALSE | CLK_ADDRESS_CLAMP_TO_EDGE | CLK_FILTER_NEAREST, integer
  * coordinates (textureAtlas.h:8,15); array layer clamped to [0, layers-1] (OpenCL 1.2 8.4). */
 cl_float4 ocl_read_image_array(const ShimImage* img, void* smp, cl_int4 c)
@@ -391,3 +408,18 @@ void ref_math(int which, int n, const float* a, const float* b, float* out) {
     }
 }
 } /* extern "C" */
+
+/* the reference `filter` kernel (tonemap/include/post_processing_filter.cl:5-51), one call per work-item */
+extern "C" void filter(int width, int height, float exposure, const unsigned long* input, unsigned* res, int type);
+extern "C" void ref_filter(int n, int width, int height, float exposure, const uint64_t* input, uint32_t* res, int type) {
+    for (int i = 0; i < n; i++) {
+        tls_gid = (size_t)i;
+        filter(width, height, exposure, (const unsigned long*)input, res, type);
+    }
+}
+extern "C" void ref_pow(int n, const float* a, const float* b, float* out) {
+    for (int i = 0; i < n; i++) {
+        cl_float3 r = ocl_pow3((cl_float3){a[i], a[i], a[i]}, (cl_float3){b[i], b[i], b[i]});
+        out[i] = r.x;
+    }
+}

@@ -7,6 +7,9 @@ Each file holds, for one named scene of tests/golden_scenes.py: the sha256 of th
 inputs, the `res` buffer after N_PASSES passes with the java.util.Random(0) seed stream, the
 `preview` ARGB image, and per-trace hit records + radiance for RECORD_GIDS at seed[0].
 kats.npz holds the function-level known answers (PCG stream, seed stream, sun basis, builtins).
+filter.npz (`python tests/golden/generate.py filter` writes only this one) holds the reference tone-map
+kernel (tonemap/include/post_processing_filter.cl, compiled in place the same way): sample values,
+exposures, and the ARGB words for every filter type, plus pow known answers.
 """
 import os
 import sys
@@ -22,9 +25,35 @@ from chunkyclplugin_amd import scenes  # noqa: E402
 from oracle import binding  # noqa: E402
 
 
+FILTER_EXPOSURES = (1.0, 0.37, 1.5)
+FILTER_TYPES = (0, 1, 2, 3, 7)
+
+
+def filter_samples():
+    """Sample-buffer values inside the domain where the reference's float -> uint conversion is defined."""
+    rng = np.random.default_rng(2024)
+    x = np.concatenate([rng.uniform(0, 2, 3000), 10.0 ** rng.uniform(-45, 6, 2400), rng.uniform(0, 0.02, 594),
+                        [0.0, 0.004, 1.0, 1e-310, 5e-324, 1e6]])
+    rng.shuffle(x)
+    return x
+
+
+def write_filter(ref):
+    x = filter_samples()
+    out = np.stack([np.stack([ref.filter(x, e, t) for e in FILTER_EXPOSURES]) for t in FILTER_TYPES])
+    rng = np.random.default_rng(7)
+    pa = np.concatenate([rng.uniform(0, 4, 3000), 10.0 ** rng.uniform(-44, 8, 1000)]).astype(np.float32)
+    pb = np.concatenate([rng.uniform(-3, 3, 2000), np.full(2000, 1.0 / 2.2)]).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "filter.npz"), samples=x, exposures=np.array(FILTER_EXPOSURES),
+                        types=np.array(FILTER_TYPES), argb=out, pow_a=pa, pow_b=pb, pow=ref.pow(pa, pb))
+    print("filter written", out.shape)
+
+
 def main():
     ref = binding.ref()
     assert ref is not None, "needs /root/reference"
+    if "filter" in sys.argv[1:]:
+        return write_filter(ref)
     seeds = scenes.java_random_ints(gs.N_PASSES)
     for name in gs.NAMES:
         sc = gs.make(name)
@@ -56,6 +85,7 @@ def main():
         sin=ref.math(0, xs), cos=ref.math(1, xs), asin=ref.math(2, us), acos=ref.math(3, us),
         atan2=ref.math(4, ya, xa), fmod1=ref.math(5, xs), sun=sun, sun_basis=ref.sun_basis(sun))
     print("kats written")
+    write_filter(ref)
 
 
 if __name__ == "__main__":
