@@ -115,6 +115,17 @@ JNIEXPORT void JNICALL J(renderPreview)(JNIEnv* env, jclass, jlong r, jintArray 
     env->ReleaseIntArrayElements(out, p, 0);
     CHECK(rc);
 }
+JNIEXPORT void JNICALL J(filterFrame)(JNIEnv* env, jclass, jlong ctx, jint width, jint height, jdouble exposure,
+                                      jdoubleArray input, jintArray out, jint type) {
+    jdouble* in = env->GetDoubleArrayElements(input, nullptr);
+    jint* p = env->GetIntArrayElements(out, nullptr);
+    int rc = CHUNKY_E_INVALID;
+    if ((jlong)env->GetArrayLength(input) >= 3LL * width * height && (jlong)env->GetArrayLength(out) >= (jlong)width * height)
+        rc = chunky_filter_frame((chunky_ctx*)ctx, width, height, exposure, in, (int32_t*)p, type);
+    env->ReleaseDoubleArrayElements(input, in, JNI_ABORT);
+    env->ReleaseIntArrayElements(out, p, 0);
+    CHECK(rc);
+}
 JNIEXPORT jint JNICALL J(renderRun)(JNIEnv* env, jclass, jlong r, jdoubleArray samples, jint sceneSpp, jint target,
                                     jint interval, jobject supplier) {
     PostRender pr{env, supplier, nullptr};

@@ -44,6 +44,10 @@ public final class HipNative {
     public static native int renderRun(long render, double[] sampleBuffer, int sceneSpp, int targetSpp,
                                        int mergeInterval, java.util.function.BooleanSupplier postRender);
 
+    // tone mapping — replaces the buffers + launch of GpuPostProcessingFilter.java:40-65
+    public static native void filterFrame(long ctx, int width, int height, double exposure, double[] input,
+                                          int[] argbOut, int type);
+
     public static final int PALETTE_BLOCK = 0, PALETTE_MATERIAL = 1, PALETTE_AABB = 2, PALETTE_QUAD = 3, PALETTE_TRIG = 4;
     public static final int BVH_WORLD = 0, BVH_ACTOR = 1;
 }
