@@ -214,11 +214,19 @@ RT_FN void rt_mirror_linear(float s, int w, int* i0, int* i1, float* a) {
 
 /* ---- pow (the tone-map kernel, reference tonemap/include/post_processing_filter.cl:24-44) --------
  * OpenCL bounds pow at 16 ULP; this definition is x^y = 2^(y*log2|x|) evaluated in binary64 from
- * + - * / fma only and rounded once to binary32 (about 0.5 ULP), with C99's special cases.  binary64
- * arithmetic is IEEE-exact on x86-64 and gfx950 alike, so host and device agree bit for bit. */
+ * + - * fma (and one binary32 division) only and rounded once to binary32 (<= 0.51 ULP), with C99's special
+ * cases.  These operations are IEEE-exact on x86-64 and gfx950 alike, so host and device agree bit for bit. */
+/* A binary64 constant of a polynomial: on the device it is pinned to a scalar register pair, so that each Horner
+ * step is one v_fma_f64 with a scalar addend instead of a 64-bit register copy plus v_fmac_f64 (the constants
+ * cannot be literals of a VOP3 instruction).  Same value either way. */
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_FN double rt_kd(double c) { asm("" : "+s"(c)); return c; }
+#else
+RT_FN double rt_kd(double c) { return c; }
+#endif
 RT_FN unsigned long long rt_d2u(double d) { unsigned long long u; __builtin_memcpy(&u, &d, 8); return u; }
 RT_FN double rt_u2d(unsigned long long u) { double d; __builtin_memcpy(&d, &u, 8); return d; }
-/* log2 of a positive, finite, normal double */
+/* log2 of a positive, finite, normal double, to about 2^-38 relative (the result feeds a binary32) */
 RT_FN double rt_log2_d(double x) {
     const unsigned long long u = rt_d2u(x);
     int e = (int)((u >> 52) & 0x7ffu) - 1023;
@@ -227,39 +235,39 @@ RT_FN double rt_log2_d(double x) {
         m *= 0.5;
         e += 1;
     }
-    /* ln m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716: odd series to s^21 (next term < 2e-18) */
-    const double s = (m - 1.0) / (m + 1.0), z = s * s;
-    double p = 1.0 / 21.0;
-    p = __builtin_fma(p, z, 1.0 / 19.0);
-    p = __builtin_fma(p, z, 1.0 / 17.0);
-    p = __builtin_fma(p, z, 1.0 / 15.0);
-    p = __builtin_fma(p, z, 1.0 / 13.0);
-    p = __builtin_fma(p, z, 1.0 / 11.0);
-    p = __builtin_fma(p, z, 1.0 / 9.0);
-    p = __builtin_fma(p, z, 1.0 / 7.0);
-    p = __builtin_fma(p, z, 1.0 / 5.0);
-    p = __builtin_fma(p, z, 1.0 / 3.0);
-    p = __builtin_fma(p, z, 1.0);
+    /* ln m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716.  1/(m+1): a binary32 quotient (exactly rounded on both
+     * sides) refined by one Newton step in binary64 -> 2^-46; a binary64 division costs three times as much on
+     * the GPU and its last bits are not needed. */
+    const double d = m + 1.0;
+    const double r0 = (double)(1.0f / (float)d);
+    const double r = r0 * __builtin_fma(-d, r0, 2.0);
+    const double s = (m - 1.0) * r, z = s * s;
+    /* odd series to s^15 (next term z^8/17 < 2^-44) */
+    double p = rt_kd(1.0 / 15.0);
+    p = __builtin_fma(p, z, rt_kd(1.0 / 13.0));
+    p = __builtin_fma(p, z, rt_kd(1.0 / 11.0));
+    p = __builtin_fma(p, z, rt_kd(1.0 / 9.0));
+    p = __builtin_fma(p, z, rt_kd(1.0 / 7.0));
+    p = __builtin_fma(p, z, rt_kd(1.0 / 5.0));
+    p = __builtin_fma(p, z, rt_kd(1.0 / 3.0));
+    p = __builtin_fma(p, z, rt_kd(1.0));
     return __builtin_fma((2.0 * s) * p, 1.4426950408889634 /* 1/ln 2 */, (double)e);
 }
-/* 2^t for |t| <= 200 */
+/* 2^t for |t| <= 200, to about 2^-40 relative */
 RT_FN double rt_exp2_d(double t) {
     const double n = __builtin_rint(t);
-    const double f = (t - n) * 0.6931471805599453; /* |f| <= 0.3466; Taylor to f^13 (next term < 5e-18) */
-    double p = 1.0 / 6227020800.0;
-    p = __builtin_fma(p, f, 1.0 / 479001600.0);
-    p = __builtin_fma(p, f, 1.0 / 39916800.0);
-    p = __builtin_fma(p, f, 1.0 / 3628800.0);
-    p = __builtin_fma(p, f, 1.0 / 362880.0);
-    p = __builtin_fma(p, f, 1.0 / 40320.0);
-    p = __builtin_fma(p, f, 1.0 / 5040.0);
-    p = __builtin_fma(p, f, 1.0 / 720.0);
-    p = __builtin_fma(p, f, 1.0 / 120.0);
-    p = __builtin_fma(p, f, 1.0 / 24.0);
-    p = __builtin_fma(p, f, 1.0 / 6.0);
-    p = __builtin_fma(p, f, 0.5);
-    p = __builtin_fma(p, f, 1.0);
-    p = __builtin_fma(p, f, 1.0);
+    const double f = (t - n) * 0.6931471805599453; /* |f| <= 0.3466; Taylor to f^10 (next term < 2^-42) */
+    double p = rt_kd(1.0 / 3628800.0);
+    p = __builtin_fma(p, f, rt_kd(1.0 / 362880.0));
+    p = __builtin_fma(p, f, rt_kd(1.0 / 40320.0));
+    p = __builtin_fma(p, f, rt_kd(1.0 / 5040.0));
+    p = __builtin_fma(p, f, rt_kd(1.0 / 720.0));
+    p = __builtin_fma(p, f, rt_kd(1.0 / 120.0));
+    p = __builtin_fma(p, f, rt_kd(1.0 / 24.0));
+    p = __builtin_fma(p, f, rt_kd(1.0 / 6.0));
+    p = __builtin_fma(p, f, rt_kd(0.5));
+    p = __builtin_fma(p, f, rt_kd(1.0));
+    p = __builtin_fma(p, f, rt_kd(1.0));
     return p * rt_u2d((unsigned long long)((int)n + 1023) << 52);
 }
 RT_FN float rt_pow(float x, float y) {
