@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libchunky_hip.so")
 HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "chunky_hip.h")
 SOURCES = ["kernels.hip", "capi.hip", "widetree.cpp"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 MAX_TRACES = 10
 HIT_DTYPE = np.dtype([("hit", "<i4"), ("material", "<i4"), ("distance", "<f4"), ("normal", "<f4", 3),
