@@ -25,8 +25,10 @@ struct LdsStack {
 
 // Leaf lookup of K/octree.h:81-89: cell (bx,by,bz) -> block pointer `data` and leaf `level`.
 // TREE = 0 walks the reference layout from the root, one bit per level; TREE = -1 walks the wide
-// re-layout (widetree.hpp) with per-level bit counts from the scene view; TREE = n > 0 walks a wide
-// tree of n levels of 3 bits (compile-time shifts) — same (data, level) for every cell.
+// re-layout (widetree.hpp) with per-level bit counts from the scene view; TREE = 16 + n walks the
+// default split of widetree.cpp — one dense top node of S.wide_bits[0] bits per axis (a wave-uniform
+// value) over n levels of 3 bits (compile-time shifts): two dependent reads per cell for a 512^3 world
+// where the reference descends nine — same (data, level) for every cell.
 // `kind`: 0 full cube, 1 other model, 2 cannot be hit (air, invisible, ANY_TYPE); the reference
 // layout carries no kinds, so every non-air leaf reports 1 there (the general test handles all types).
 template <int TREE>
@@ -44,13 +46,20 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
     } else {
         const uint32_t* __restrict__ tree = S.wide;
         int e = 0;
-        if (TREE > 0) {
+        if (TREE >= 16) {
+            constexpr int N3 = TREE - 16;
+            {
+                // the cell is inside the world, so the top index needs no masks
+                const int tb = S.wide_bits[0];
+                const unsigned idx = (((((unsigned)bx >> (3 * N3)) << tb) | ((unsigned)by >> (3 * N3))) << tb) | ((unsigned)bz >> (3 * N3));
+                // byte offset in 32 bits (the builder keeps the array under 2^30 entries): SGPR base + VGPR offset
+                e = *(const int*)((const char*)tree + (idx << 2));
+            }
 #pragma unroll
-            for (int i = 0; i < TREE; i++) {
-                if (i == 0 || e >= 0) {
-                    const int sh = 3 * (TREE - 1 - i);
+            for (int i = 0; i < N3; i++) {
+                if (e >= 0) {
+                    const int sh = 3 * (N3 - 1 - i);
                     const unsigned idx = (((unsigned)bx >> sh) & 7u) << 6 | (((unsigned)by >> sh) & 7u) << 3 | (((unsigned)bz >> sh) & 7u);
-                    // byte offset in 32 bits (the builder keeps the array under 2^30 entries): SGPR base + VGPR offset
                     e = *(const int*)((const char*)tree + (((unsigned)e + idx) << 2));
                 }
             }
@@ -1136,11 +1145,11 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
             if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
             n_cu = prop.multiProcessorCount;
         }
-        // tree kind: 0 reference layout, n = 1..5 wide tree of n 3-bit levels, -1 any other wide split
+        // tree kind: 0 reference layout, 16 + n = dense top over n <= 3 levels of 3 bits, -1 any other wide split
         int tree = 0;
         if (wide) {
-            tree = S.wide_nlev <= 5 ? S.wide_nlev : -1;
-            for (int i = 0; i < S.wide_nlev; i++)
+            tree = S.wide_nlev <= 4 ? 16 + S.wide_nlev - 1 : -1;
+            for (int i = 1; i < S.wide_nlev; i++)
                 if (S.wide_bits[i] != 3) tree = -1;
         }
         typedef void (*Kernel)(WaveArgs);
@@ -1162,34 +1171,32 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         Kernel k;
         if (has_bvh && !stats && group > 1) {
             if (group == 16)
-                k = tree == 3 ? render_waves<3, false, 16, true> : (tree == 4 ? render_waves<4, false, 16, true> : render_waves<-1, false, 16, true>);
+                k = tree == 17 ? render_waves<17, false, 16, true> : (tree == 18 ? render_waves<18, false, 16, true> : render_waves<-1, false, 16, true>);
             else
-                k = tree == 3 ? render_waves<3, false, 8, true> : (tree == 4 ? render_waves<4, false, 8, true> : render_waves<-1, false, 8, true>);
+                k = tree == 17 ? render_waves<17, false, 8, true> : (tree == 18 ? render_waves<18, false, 8, true> : render_waves<-1, false, 8, true>);
         } else if (has_bvh) {
             k = stats ? render_waves<-1, true, 1, true> : render_waves<-1, false, 1, true>;
         } else if (stats) {
-            k = tree == 3 ? (group == 1 ? render_waves<3, true, 1> : render_waves<3, true, 8>)
-                          : (group == 1 ? render_waves<-1, true, 1> : render_waves<-1, true, 8>);
+            k = tree == 17 ? (group == 1 ? render_waves<17, true, 1> : render_waves<17, true, 8>)
+                           : (group == 1 ? render_waves<-1, true, 1> : render_waves<-1, true, 8>);
         } else if (group == 1) {
             switch (tree) {
                 case 0: k = render_waves<0, false, 1>; break;
-                case 1: k = render_waves<1, false, 1>; break;
-                case 2: k = render_waves<2, false, 1>; break;
-                case 3: k = render_waves<3, false, 1>; break;
-                case 4: k = render_waves<4, false, 1>; break;
-                case 5: k = render_waves<5, false, 1>; break;
+                case 16: k = render_waves<16, false, 1>; break;
+                case 17: k = render_waves<17, false, 1>; break;
+                case 18: k = render_waves<18, false, 1>; break;
+                case 19: k = render_waves<19, false, 1>; break;
                 default: k = render_waves<-1, false, 1>; break;
             }
         } else if (group == 16) {
-            k = tree == 3 ? render_waves<3, false, 16> : render_waves<-1, false, 16>;
+            k = tree == 17 ? render_waves<17, false, 16> : (tree == 18 ? render_waves<18, false, 16> : render_waves<-1, false, 16>);
         } else {
             switch (tree) {
                 case 0: k = render_waves<0, false, 8>; break;
-                case 1: k = render_waves<1, false, 8>; break;
-                case 2: k = render_waves<2, false, 8>; break;
-                case 3: k = render_waves<3, false, 8>; break;
-                case 4: k = render_waves<4, false, 8>; break;
-                case 5: k = render_waves<5, false, 8>; break;
+                case 16: k = render_waves<16, false, 8>; break;
+                case 17: k = render_waves<17, false, 8>; break;
+                case 18: k = render_waves<18, false, 8>; break;
+                case 19: k = render_waves<19, false, 8>; break;
                 default: k = render_waves<-1, false, 8>; break;
             }
         }

@@ -6,12 +6,15 @@
 namespace chunky {
 
 int default_wide_levels(int depth, int* level_bits) {
-    // 3 bits at every level; the top level is padded when depth is not a multiple of 3, so the
-    // kernels can use compile-time shifts (a padded top node wastes at most 511 entries)
-    int nlev = depth <= 0 ? 1 : (depth + 2) / 3;
-    if (nlev > kWideMaxLevels) nlev = kWideMaxLevels;
-    for (int i = 0; i < nlev; i++) level_bits[i] = 3;
-    return nlev;
+    // one dense top node of 4..6 bits per axis (at most 64^3 entries = 1 MiB) over levels of 3 bits: the
+    // top two or three octree-node fetches of a lookup become one array read, and the kernels keep
+    // compile-time shifts for the levels below
+    if (depth < 0) depth = 0;
+    int n3 = depth <= 6 ? 0 : (depth - 6 + 2) / 3;
+    if (n3 > kWideMaxLevels - 1) n3 = kWideMaxLevels - 1;
+    level_bits[0] = depth - 3 * n3;
+    for (int i = 1; i <= n3; i++) level_bits[i] = 3;
+    return n3 + 1;
 }
 
 namespace {
