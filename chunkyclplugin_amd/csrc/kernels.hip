@@ -29,7 +29,7 @@ struct LdsStack {
 // default split of widetree.cpp — one dense top node of S.wide_bits[0] bits per axis (a wave-uniform
 // value) over n levels of 3 bits (compile-time shifts): two dependent reads per cell for a 512^3 world
 // where the reference descends nine — same (data, level) for every cell.
-// `kind`: 0 full cube, 1 other model, 2 cannot be hit (air, invisible, ANY_TYPE); the reference
+// `kind`: 0 full cube, 1 other model, 2 or 3 cannot be hit (air, invisible, ANY_TYPE); the reference
 // layout carries no kinds, so every non-air leaf reports 1 there (the general test handles all types).
 template <int TREE>
 DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind) {
@@ -73,11 +73,11 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
                 e = (int)tree[(unsigned)e + ((((ix << b) | iy) << b) | iz)];  // unsigned: 32-bit offset off an SGPR base
             }
         }
+        // three field extractions: the builder's annotation pass (widetree.cpp) has set kind 2 on air and on
+        // pointers outside the block palette, and ANY_TYPE carries kind 3; `data` means something for kinds 0, 1 only
         level = (e >> 27) & 15;
-        const unsigned code = (unsigned)e & 0x7FFFFFFu;
-        data = code == 0x7FFFFFFu ? kAnyType : (int)(code & 0x1FFFFFFu);
-        kind = (code & 0x1FFFFFFu) == 0 ? 2 : (int)(code >> 25);
-        if (kind == 3) kind = 2;
+        kind = (int)(((unsigned)e >> 25) & 3u);
+        data = (int)((unsigned)e & 0x1FFFFFFu);
     }
 }
 
@@ -103,7 +103,7 @@ DEV bool octree_hit(const SceneView& S, f3 o, f3 d, int draw_depth, Hit& h) {
         if (((bx | by | bz) >> depth) != 0) return false;  // any coordinate outside [0, 2^depth)
         int level, data, kind;
         leaf_lookup<TREE>(S, bx, by, bz, data, level, kind);
-        if (kind != 2) {  // not air (ray->material is always 0, K/octree.h:92) and able to intersect
+        if (kind < 2) {  // not air (ray->material is always 0, K/octree.h:92) and able to intersect
             float dist = block_hit(S, data, bx, by, bz, pos, d, inv, h);
             if (dist == dist) {
                 h.distance = dist_march + dist;
@@ -332,7 +332,7 @@ DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     const bool live = (L.steps < O.draw_depth) & !(L.dist_march > L.h.distance) & (((bx | by | bz) >> depth) == 0);
     int level = 0, data = 0, kind = 2;
     if (live) leaf_lookup<TREE>(S, bx, by, bz, data, level, kind);
-    const bool cand = live & (kind != 2);
+    const bool cand = live & (kind < 2);
     // leaf exit (K/octree.h:103-106) — kept only by lanes that stay in the march.  The leaf box is
     // [lv << level, (lv + 1) << level) per axis; as floats: min = float(b & -2^level) and max = min + 2^level,
     // both exact (integers below 2^24), so this is the reference's box bit for bit.
