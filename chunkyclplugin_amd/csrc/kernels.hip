@@ -32,7 +32,9 @@ struct LdsStack {
 // `kind`: 0 full cube, 1 other model, 2 or 3 cannot be hit (air, invisible, ANY_TYPE); the reference
 // layout carries no kinds, so every non-air leaf reports 1 there (the general test handles all types).
 template <int TREE>
-DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind) {
+DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind, bool inside = true) {
+    // `inside` false: the cell is not in the world; the lookup then reads cell (0, 0, 0) (callers discard it)
+    if (TREE < 16 && !inside) bx = by = bz = 0;
     if (TREE == 0) {
         const int* __restrict__ tree = S.octree;
         level = S.octree_depth;
@@ -51,7 +53,8 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
             {
                 // the cell is inside the world, so the top index needs no masks
                 const int tb = S.wide_bits[0];
-                const unsigned idx = (((((unsigned)bx >> (3 * N3)) << tb) | ((unsigned)by >> (3 * N3))) << tb) | ((unsigned)bz >> (3 * N3));
+                unsigned idx = (((((unsigned)bx >> (3 * N3)) << tb) | ((unsigned)by >> (3 * N3))) << tb) | ((unsigned)bz >> (3 * N3));
+                idx = inside ? idx : 0u;  // the levels below mask their index bits: any bx, by, bz stay inside the node
                 // byte offset in 32 bits (the builder keeps the array under 2^30 entries): SGPR base + VGPR offset
                 e = *(const int*)((const char*)tree + (idx << 2));
             }
@@ -288,17 +291,40 @@ struct LaneState {
     // and the shadow ray's own copy of record.distance
     int bvh_cur, bvh_top, bvh_which;
     float bvh_dist;
+    f3 far;  // per axis 1.0 where the ray runs towards +axis (inv > 0), else 0.0: selects a leaf's exit plane
     // main record
     Hit h;
     f3 point;
 };
 
+// (int)floor(x) in one instruction, saturating like v_cvt_i32_f32 (math self test 18).  NaN converts to
+// INT_MAX: a cell outside any world, which ends the march like the INT_MIN of the reference's x86 build does.
+DEV int floor_to_int(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// AABB_exit of the leaf that holds cell (bx, by, bz) = floor(po) (K/octree.h:103-106, K/primitives.h:52-61).
+// The leaf box is [lv << level, (lv + 1) << level) per axis; as floats: min = float(b & -2^level) and
+// max = min + 2^level, both exact (integers below 2^24).  The reference takes, per axis,
+// fmax((min - p)*inv, (max - p)*inv).  p lies in [min, max), rounding is monotonic, so the larger product is the
+// one with the plane the ray leaves through — max if inv > 0, else min — and only that one is evaluated
+// (L.far selects it; the fma is exact).  The one case where that product is NaN while the reference's fmax
+// returns the other one (p == min with inv == -inf: NaN against -inf) is restored by the fmax with -inf.
+DEV float leaf_exit_distance(const LaneState& L, f3 po, int bx, int by, int bz, int level) {
+    const int keep = -1 << level;
+    const float size = __builtin_ldexpf(1.0f, level);
+    const float x0 = (float)(bx & keep), y0 = (float)(by & keep), z0 = (float)(bz & keep);
+    const float tx = rt_fmax((rt_fma(L.far.x, size, x0) - po.x) * L.inv.x, -rt_inf());
+    const float ty = rt_fmax((rt_fma(L.far.y, size, y0) - po.y) * L.inv.y, -rt_inf());
+    const float tz = rt_fmax((rt_fma(L.far.z, size, z0) - po.z) * L.inv.z, -rt_inf());
+    return rt_fmin(tx, rt_fmin(ty, tz));
+}
+
 template <int TREE>
 DEV void leaf_exit(const SceneView& S, LaneState& L, f3 po, int bx, int by, int bz, int level) {
-    int lx = bx >> level, ly = by >> level, lz = bz >> level;
-    L.dist_march += box_exit((float)(lx << level), (float)((lx + 1) << level), (float)(ly << level),
-                             (float)((ly + 1) << level), (float)(lz << level), (float)((lz + 1) << level), po, L.inv) +
-                    kOffset;
+    L.dist_march += leaf_exit_distance(L, po, bx, by, bz, level) + kOffset;
     L.steps += 1;
 }
 
@@ -307,6 +333,7 @@ template <int END>
 DEV int trace_setup(const SceneView& S, LaneState& L) {
     const int depth = S.octree_depth;
     L.inv = rcp3(L.d);
+    L.far = mk3(L.inv.x > 0 ? 1.0f : 0.0f, L.inv.y > 0 ? 1.0f : 0.0f, L.inv.z > 0 ? 1.0f : 0.0f);
     L.dist_march = 0;
     L.steps = 0;
     L.oct_hit = false;
@@ -328,23 +355,19 @@ DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
     const int depth = S.octree_depth;
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
-    int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
+    int bx = floor_to_int(po.x), by = floor_to_int(po.y), bz = floor_to_int(po.z);
     const bool live = (L.steps < O.draw_depth) & !(L.dist_march > L.h.distance) & (((bx | by | bz) >> depth) == 0);
-    int level = 0, data = 0, kind = 2;
-    if (live) leaf_lookup<TREE>(S, bx, by, bz, data, level, kind);
+    // a lane whose trace has ended reads cell (0, 0, 0): any entry will do, its outcome is discarded
+    int level, data, kind;
+    leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, live);
     const bool cand = live & (kind < 2);
-    // leaf exit (K/octree.h:103-106) — kept only by lanes that stay in the march.  The leaf box is
-    // [lv << level, (lv + 1) << level) per axis; as floats: min = float(b & -2^level) and max = min + 2^level,
-    // both exact (integers below 2^24), so this is the reference's box bit for bit.
-    const int keep = -1 << level;
-    const float size = __builtin_ldexpf(1.0f, level);
-    const float x0 = (float)(bx & keep), y0 = (float)(by & keep), z0 = (float)(bz & keep);
-    const float step = box_exit(x0, x0 + size, y0, y0 + size, z0, z0 + size, po, L.inv) + kOffset;
+    const float step = leaf_exit_distance(L, po, bx, by, bz, level) + kOffset;  // kept only by lanes that stay in the march
     const bool go = live & !cand;
     L.dist_march = go ? L.dist_march + step : L.dist_march;
     L.steps = go ? L.steps + 1 : L.steps;
-    L.cand_data = cand ? data : L.cand_data;
-    L.cand_level = cand ? level : L.cand_level;
+    // only lanes in the march are here, and for them the candidate is dead unless it is set now
+    L.cand_data = data;
+    L.cand_level = level;
     return !live ? END : (cand ? ST_BLOCK : ST_MARCH);
 }
 
@@ -1037,6 +1060,7 @@ __global__ void math_selftest_kernel(int which, int n, const float* __restrict__
         case 14: r = (float)((double)((unsigned)(int)x & 0xFF) / 255.0); break;
         case 15: r = (float)(-0.5 + (double)(x * y)); break;
         case 16: r = rt_pow(x, y); break;
+        case 18: r = (float)floor_to_int(x); break;
         case 17: r = (float)((double)x * (double)y); break;
         default: break;
     }

@@ -94,6 +94,20 @@ def test_device_math_bit_equals_host(gpu_instance, port, which):
     assert ok.all(), (which, a[~ok][:4], b[~ok][:4], dev[~ok][:4], host[~ok][:4])
 
 
+def test_device_floor_to_int(gpu_instance):
+    """v_cvt_flr_i32_f32 (self test 18) == (int)floor(x), saturating outside the int range; NaN gives INT_MAX
+    (a cell outside any world, like the INT_MIN the x86 build of the reference produces there)."""
+    rng = np.random.default_rng(18)
+    a = np.concatenate([rng.uniform(-600, 600, 40000), rng.normal(size=20000) * 10.0 ** rng.integers(-8, 12, 20000),
+                        np.arange(-70, 70) * 0.5, [0.0, -0.0, np.inf, -np.inf, np.nan, 2147483520.0, -2147483648.0, 3e9, -3e9,
+                                                  0.99999994, -1e-45, 1e-45, 8388607.5, -8388607.5]]).astype(np.float32)
+    dev = gpu_instance.selftest_math(18, a, a)
+    with np.errstate(invalid="ignore"):
+        want = np.clip(np.floor(a.astype(np.float64)), -2147483648.0, 2147483647.0)
+    want = np.where(np.isnan(a), 2147483647.0, want).astype(np.int64).astype(np.float32)
+    np.testing.assert_array_equal(dev, want)
+
+
 def _fma(a, b, c):
     return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)  # exact product in f64
 
