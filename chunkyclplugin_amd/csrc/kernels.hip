@@ -350,25 +350,48 @@ DEV int trace_setup(const SceneView& S, LaneState& L) {
 // Written without early returns: the arithmetic runs for every lane of the phase (it is harmless for
 // a lane whose trace has ended), only the tree reads are guarded, and the outcome is three selects —
 // nested exits cost a copy of every live-out per exit in the compiled code.
-template <int TREE, int END>
-DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
+// One march step (K/octree.h:66-106) for the lanes of `marching`, written for the whole wave with no branch
+// around it and no per-lane state flags: who is marching, who found a candidate and whose trace ended are
+// 64-bit lane masks in scalar registers, combined with scalar instructions; the vector unit only sees the
+// arithmetic.  A lane outside `marching` computes on stale values and keeps none of it — its tree read is made
+// safe by the in-world test alone.  Returns the candidates and the lanes still alive; `data` / `level` are
+// the leaf every lane looked at (for a lane that has stopped marching they keep coming out the same: its
+// position no longer moves).
+typedef unsigned long long LaneMask;
+DEV bool in_mask(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+template <int TREE>
+DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneMask marching, LaneMask& cand_out,
+                    LaneMask& live_out, int& data, int& level) {
     const int depth = S.octree_depth;
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
     int bx = floor_to_int(po.x), by = floor_to_int(po.y), bz = floor_to_int(po.z);
-    const bool live = (L.steps < O.draw_depth) & !(L.dist_march > L.h.distance) & (((bx | by | bz) >> depth) == 0);
-    // a lane whose trace has ended reads cell (0, 0, 0): any entry will do, its outcome is discarded
-    int level, data, kind;
-    leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, live);
-    const bool cand = live & (kind < 2);
-    const float step = leaf_exit_distance(L, po, bx, by, bz, level) + kOffset;  // kept only by lanes that stay in the march
-    const bool go = live & !cand;
-    L.dist_march = go ? L.dist_march + step : L.dist_march;
-    L.steps = go ? L.steps + 1 : L.steps;
-    // only lanes in the march are here, and for them the candidate is dead unless it is set now
-    L.cand_data = data;
-    L.cand_level = level;
-    return !live ? END : (cand ? ST_BLOCK : ST_MARCH);
+    const bool inside = ((bx | by | bz) >> depth) == 0;
+    const LaneMask live = marching & __ballot(L.steps < O.draw_depth) & __ballot(!(L.dist_march > L.h.distance)) & __ballot(inside);
+    int kind;
+    leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, inside);
+    const LaneMask hittable = __ballot(kind < 2);
+    const LaneMask cand = live & hittable, go = live & ~hittable;
+    const float step = leaf_exit_distance(L, po, bx, by, bz, level) + kOffset;  // K/octree.h:103-106
+    const bool advance = in_mask(go);
+    L.dist_march = advance ? L.dist_march + step : L.dist_march;
+    L.steps = advance ? L.steps + 1 : L.steps;
+    cand_out = cand;
+    live_out = live;
+}
+
+// The same step for the lanes that call it (inside a branch on the lane's state): returns the next state.
+template <int TREE, int END>
+DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
+    const LaneMask here = __ballot(true);
+    LaneMask cand, live;
+    int data, level;
+    march_step<TREE>(S, O, L, here, cand, live, data, level);
+    const bool c = in_mask(cand);
+    L.cand_data = c ? data : L.cand_data;
+    L.cand_level = c ? level : L.cand_level;
+    return c ? ST_BLOCK : (in_mask(here & ~live) ? END : ST_MARCH);
 }
 
 template <int TREE, int END>
@@ -910,17 +933,28 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
             } else {
                 // stay in the march while it keeps the majority: an inner loop whose back-edge carries
                 // only what MARCH changes (the outer loop's back-edge re-shuffles ~25 state registers)
-                int nm = n_march, nb, ns;
+                // The lanes' states stay untouched inside the loop; they are written once when it is left.
+                int nm = n_march, nb = n_block, ns = n_shade;
+                const LaneMask entered = __ballot(st == ST_MARCH);
+                LaneMask marching = entered, to_block = 0;
+                int data, level;
                 do {
                     if (STATS) {  // every inner iteration counts as one MARCH execution (cycles are added below)
                         prof[0] += 1;
                         prof[1] += (unsigned long long)nm;
                     }
-                    if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
-                    nm = count_lanes(st == ST_MARCH);
-                    nb = count_lanes(st == ST_BLOCK);
-                    ns = count_lanes(st == ST_SHADE);
+                    LaneMask cand, live;
+                    march_step<TREE>(Sm, Om, L, marching, cand, live, data, level);
+                    nb += __popcll(cand);
+                    ns += __popcll(marching & ~live);
+                    to_block |= cand;
+                    marching = live & ~cand;
+                    nm = __popcll(marching);
                 } while (nm > 0 && nm >= nb && nm >= ns);
+                const bool found = in_mask(to_block);
+                L.cand_data = found ? data : L.cand_data;
+                L.cand_level = found ? level : L.cand_level;
+                st = found ? ST_BLOCK : (in_mask(entered & ~marching & ~to_block) ? END : st);
                 if (STATS) {  // undo the one execution the common accounting below adds
                     prof[0] -= 1;
                     prof[1] -= (unsigned long long)n_march;
