@@ -591,7 +591,7 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
         L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, e);
         if (main_trace) return ST_NEXT;
     }
-    bool bounce = true;
+    bool bounce = true, to_sun = false;
     if (main_trace) {
         L.point = L.o + L.d * (L.h.distance - kOffset);
         // applyRayColor (K/kernel.h:33-44)
@@ -600,23 +600,58 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
         L.throughput = L.throughput * c;
         L.radiance = L.radiance + (c * (L.h.emittance * O.emitter_scale)) * L.throughput;
         if (S.sun_flags & 1) {
-            L.d = sun_sample(S, L.rng);
-            L.h.emittance = rt_fabs(dot(L.d, L.h.normal));
-            L.shadow_emit = L.h.emittance;
-            L.shadow = true;
+            to_sun = true;
             bounce = false;
         }
     } else {
         L.shadow = false;
     }
-    if (bounce) {
-        // nextPath (K/kernel.h:46-98)
-        L.o = L.point;
-        L.d = diffuse_bounce(L.h.normal, L.rng);
-        L.o = L.o + L.d * kOffset;
-        L.depth += 1;
-        L.h.distance = rt_inf();
-        if (!(L.depth < O.max_depth)) return ST_NEXT;
+    // Sun_sampleDirection (K/sky.h:68-93) for the lanes that start a shadow ray, nextPath (K/kernel.h:46-98)
+    // for the lanes that bounce.  A lane does one or the other, and both have the same skeleton — two draws,
+    // sin/cos of 2*pi*x2, a square root, a vector, its reciprocal length — so the expensive steps are issued
+    // once for both kinds of lane and only the cheap vector algebra in between is specific.
+    {
+        const float x1 = rt_pcg_float(&L.rng), x2 = rt_pcg_float(&L.rng);
+        float sn, cs;
+        rt_sincos(2 * RT_PI_F * x2, &sn, &cs);
+        const float cos_a = 1 - x1 + x1 * S.sun_radius_cos;          // sun: cosine of the angle off the sun axis
+        const float root = rt_sqrt(to_sun ? 1 - cos_a * cos_a : x1);  // sun: sin_a; bounce: r
+        const f3 n = L.h.normal;
+        f3 a;        // sun: the unnormalised direction; bounce: the unnormalised tangent u
+        float len2;  // its squared length, each written as the reference writes it
+        if (to_sun) {
+            const f3 u = S.su * (cs * root), v = S.sv * (sn * root), w = S.sw * cos_a;
+            a = (u * v) + w;  // component-wise product, as the reference has it
+            len2 = dot(a, a);
+        } else {
+            float xx, xy, xz = 0;
+            if ((double)rt_fabs(n.x) > 0.1) {
+                xx = 0;
+                xy = 1;
+            } else {
+                xx = 1;
+                xy = 0;
+            }
+            a = mk3(xy * n.z - xz * n.y, xz * n.x - xx * n.z, xx * n.y - xy * n.x);
+            len2 = a.x * a.x + a.y * a.y + a.z * a.z;
+        }
+        const float rl = 1 / rt_sqrt(len2);
+        a = a * rl;
+        if (to_sun) {
+            L.d = a;
+            L.h.emittance = rt_fabs(dot(L.d, n));
+            L.shadow_emit = L.h.emittance;
+            L.shadow = true;
+        } else {
+            const float tx = root * cs, ty = root * sn, tz = rt_sqrt(1 - x1);
+            const float vx = a.y * n.z - a.z * n.y, vy = a.z * n.x - a.x * n.z, vz = a.x * n.y - a.y * n.x;
+            L.o = L.point;
+            L.d = f3{a.x * tx + vx * ty + n.x * tz, a.y * tx + vy * ty + n.y * tz, a.z * tx + vz * ty + n.z * tz};
+            L.o = L.o + L.d * kOffset;
+            L.depth += 1;
+            L.h.distance = rt_inf();
+            if (!(L.depth < O.max_depth)) return ST_NEXT;
+        }
     }
     return ST_SETUP;
 }
