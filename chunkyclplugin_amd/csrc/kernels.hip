@@ -749,33 +749,30 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
             make_float4(L.radiance.x, L.radiance.y, L.radiance.z, __int_as_float((L.serial << 8) | L.pass));
         st = ST_IDLE;  // free for another pass
     }
-    // ---- fold parked radiances strictly in pass order: lane 0 of the group serves open pixel 0, lane 1
-    //      open pixel 1, so the fold code is issued once for both ----
+    // ---- fold parked radiances strictly in pass order.  Six lanes of the group work at once: lanes 0-2 take
+    //      the R, G, B channel of open pixel 0, lanes 3-5 those of open pixel 1, so the fold code — one exact
+    //      division per pass and channel, K/rayTracer.cl:109-112 — is issued once for all six ----
     int4* const hdr4 = (int4*)lds.hdr;  // per open pixel: {gid, fold, issue, serial}, {mean.x, mean.y, mean.z, -}
-    if (sub < 2) {
-        const int k = sub;
+    if (sub < 6) {
+        const int k = sub >= 3 ? 1 : 0, ch = sub - 3 * k;
         const int4 h = hdr4[2 * k];
         if (h.x >= 0) {
-            const int4 m = hdr4[2 * k + 1];
-            f3 mean = mk3(__int_as_float(m.x), __int_as_float(m.y), __int_as_float(m.z));
+            float mean = __int_as_float(lds.hdr[8 * k + H_MEAN + ch]);
+            const float* const ring = (const float*)(lds.rad + k * kRing);
             int fn = h.y;
             while (fn < n_passes) {
-                const float4 c = lds.rad[k * kRing + (fn & (kRing - 1))];
-                if (__float_as_int(c.w) != ((h.w << 8) | fn)) break;
-                const int spp = first_spp + fn;  // K/rayTracer.cl:109-112
-                const float fs = (float)spp, fs1 = (float)(spp + 1);
-                mean = f3{(mean.x * fs + c.x) / fs1, (mean.y * fs + c.y) / fs1, (mean.z * fs + c.z) / fs1};
+                const float* const c = ring + 4 * (fn & (kRing - 1));
+                if (__float_as_int(c[3]) != ((h.w << 8) | fn)) break;
+                const int spp = first_spp + fn;
+                mean = (mean * (float)spp + c[ch]) / (float)(spp + 1);
                 fn++;
             }
             if (fn >= n_passes) {  // pixel complete
-                float* px = res + 3 * (size_t)h.x;
-                px[0] = mean.x;
-                px[1] = mean.y;
-                px[2] = mean.z;
-                hdr4[2 * k] = make_int4(-1, fn, h.z, h.w);
+                res[3 * (size_t)h.x + ch] = mean;
+                if (ch == 0) hdr4[2 * k] = make_int4(-1, fn, h.z, h.w);
             } else if (fn != h.y) {
-                hdr4[2 * k] = make_int4(h.x, fn, h.z, h.w);
-                hdr4[2 * k + 1] = make_int4(__float_as_int(mean.x), __float_as_int(mean.y), __float_as_int(mean.z), 0);
+                if (ch == 0) hdr4[2 * k] = make_int4(h.x, fn, h.z, h.w);
+                lds.hdr[8 * k + H_MEAN + ch] = __float_as_int(mean);
             }
         }
     }
