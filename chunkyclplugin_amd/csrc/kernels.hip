@@ -723,9 +723,20 @@ DEV int next_sample_single(const SceneView& S, const CameraView& C, const ShardV
 // the image is bit-identical for every G.  Two pixels are open per group — passes are issued from
 // the newer one while the older one waits for its last paths — so a group never drains between pixels.
 #ifndef CHUNKY_HANDOVER_BATCH
-#define CHUNKY_HANDOVER_BATCH 4
+#define CHUNKY_HANDOVER_BATCH 8
 #endif
 constexpr int kHandoverBatch = CHUNKY_HANDOVER_BATCH;
+// vote weights: the phase with the largest (waiting lanes x weight) runs next
+#ifndef CHUNKY_W_MARCH
+#define CHUNKY_W_MARCH 4
+#endif
+#ifndef CHUNKY_W_BLOCK
+#define CHUNKY_W_BLOCK 4
+#endif
+#ifndef CHUNKY_W_SHADE
+#define CHUNKY_W_SHADE 4
+#endif
+constexpr int kWMarch = CHUNKY_W_MARCH, kWBlock = CHUNKY_W_BLOCK, kWShade = CHUNKY_W_SHADE;
 constexpr int kRing = 32;  // parked radiances per open pixel; a pass is issued only inside fold + kRing
 struct GroupLds {
     float4* rad;  // [2][kRing] {r, g, b, tag}
@@ -946,7 +957,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
                     ns = count_lanes(st == ST_SHADE);
                 } while (nv > 0 && nv >= nm && nv >= nb && nv >= ns);
             }
-        } else if (n_march >= n_block && n_march >= n_shade) {
+        } else if (n_march * kWMarch >= n_block * kWBlock && n_march * kWMarch >= n_shade * kWShade) {
             ph = 0;
             // the few scalars MARCH needs are re-read here too (scalar cache hits): kept live across
             // the whole loop they are the first thing the allocator spills to VGPR lanes
@@ -982,7 +993,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
                     to_block |= cand;
                     marching = live & ~cand;
                     nm = __popcll(marching);
-                } while (nm > 0 && nm >= nb && nm >= ns);
+                } while (nm > 0 && nm * kWMarch >= nb * kWBlock && nm * kWMarch >= ns * kWShade);
                 const bool found = in_mask(to_block);
                 L.cand_data = found ? data : L.cand_data;
                 L.cand_level = found ? level : L.cand_level;
@@ -992,7 +1003,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
                     prof[1] -= (unsigned long long)n_march;
                 }
             }
-        } else if (n_block >= n_shade) {
+        } else if (n_block * kWBlock >= n_shade * kWShade) {
             ph = 1;
             const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_BLOCK) st = block_phase<TREE, END>(S, L);

@@ -16,7 +16,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libchunky_hip.so")
+LIB_PATH = os.environ.get("CHUNKY_HIP_LIB") or os.path.join(PKG_DIR, "libchunky_hip.so")  # override: tuning builds (tools/variants.sh)
 HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "chunky_hip.h")
 SOURCES = ["kernels.hip", "capi.hip", "widetree.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
@@ -41,6 +41,8 @@ class ChunkyHipError(RuntimeError):
 
 
 def _needs_build() -> bool:
+    if os.environ.get("CHUNKY_HIP_LIB"):
+        return False
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)

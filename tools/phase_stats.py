@@ -11,7 +11,10 @@ from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, 
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 world = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-sc = scenes.cached_outdoor_world(chunks=32, height=256)
+kw = {}
+if os.environ.get("CHUNKY_STATS_MODELS") == "0":  # the same world with no slab / plant blocks: BLOCK then runs the cube path only
+    kw = dict(aabb_frac=0.0, quad_frac=0.0)
+sc = scenes.cached_outdoor_world(chunks=32, height=256, **kw)
 loader = HipSceneLoader(RendererInstance.get(0))
 loader.load_packed(sc)
 r = HipPathTracingRenderer(loader, sc.width, sc.height)
