@@ -737,7 +737,9 @@ constexpr int kHandoverBatch = CHUNKY_HANDOVER_BATCH;
 #define CHUNKY_W_SHADE 4
 #endif
 constexpr int kWMarch = CHUNKY_W_MARCH, kWBlock = CHUNKY_W_BLOCK, kWShade = CHUNKY_W_SHADE;
-constexpr int kRing = 32;  // parked radiances per open pixel; a pass is issued only inside fold + kRing
+// parked radiances per open pixel (a pass is issued only inside fold + ring): two per lane of the group; the rings
+// of a workgroup take 18 KB of LDS either way, which leaves room for five workgroups per CU
+constexpr int ring_size(int group) { return group >= 16 ? 32 : 16; }
 struct GroupLds {
     float4* rad;  // [2][kRing] {r, g, b, tag}
     int* hdr;     // [2][8]  {gid, fold, issue, serial, mean.x, mean.y, mean.z, -}
@@ -747,6 +749,7 @@ enum : int { H_GID = 0, H_FOLD = 1, H_ISSUE = 2, H_SERIAL = 3, H_MEAN = 4 };
 template <int TREE, int G>
 DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, WaveArgPtr A, PixelPool& pool,
                     LaneState& L, GroupLds lds, int st) {
+    constexpr int kRing = ring_size(G);
     const int first_spp = A->P.first_spp, n_passes = A->P.n;
     float* __restrict__ res = A->res;
     WorkQueue Q = arg_copy(&A->Q);
@@ -863,7 +866,10 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
 // cycles by s_memtime), summed over waves into stats[phase*3 + {0,1,2}]; used by tools/phase_stats.py.
 // BVH = false compiles the entity-BVH state out (scenes whose two BVHs are the empty sentinel).
 template <int TREE, bool STATS, int G, bool BVH = false>
-__global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) {
+// Five workgroups per CU (96 VGPRs; a march step waits on one or two dependent tree reads, and the fifth wave per
+// SIMD fills that time: +5 % over four); the entity-BVH kernels need ~125 registers and stay at four, like the
+// profiling build (its counters would spill).
+__global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(WaveArgs unused_by_name) {
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
@@ -893,6 +899,7 @@ __global__ void __launch_bounds__(256, 4) render_waves(WaveArgs unused_by_name) 
     // per-group radiance buffers behind the BVH stacks in dynamic LDS
     GroupLds glds{nullptr};
     if (G > 1) {
+        constexpr int kRing = ring_size(G);
         const unsigned stack_bytes = fresh_args()->stack_bytes;
         char* base = (char*)lds + stack_bytes + (threadIdx.x / G) * (2 * kRing * 16 + 64);
         glds.rad = (float4*)base;
@@ -1267,7 +1274,7 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
             default: break;
         }
         if (group != 1 && group != 8 && group != 16) group = 8;
-        if (group > 1) lds += (size_t)(block / group) * (2 * kRing * 16 + 64);
+        if (group > 1) lds += (size_t)(block / group) * (2 * ring_size(group) * 16 + 64);
         const bool has_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
         Kernel k;
         if (has_bvh && !stats && group > 1) {
