@@ -256,7 +256,8 @@ DEV int count_lanes(bool p) {
 
 enum : int {
     ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2,  // voted phases (+ ST_BVH)
-    ST_BVH = 9,     // one node visit of the entity BVHs
+    ST_BVH = 9,     // at a node of an entity BVH: inner-node visits are voted as one phase,
+    ST_LEAF = 11,   // the triangle tests of a leaf as another
     ST_TRACED = 10, // octree part of the trace finished (transient)
     ST_DONE = 3,   // no pixels left for this lane's group
     ST_NEXT = 4,   // path finished, radiance ready
@@ -466,79 +467,80 @@ DEV int bvh_begin(const SceneView& S, LaneState& L) {
     return ST_BVH;
 }
 
-// BVH phase: ONE node visit of Bvh_intersect (K/bvh.h:47-109) — a leaf's triangles, or the two box
-// tests of an inner node with the near-first / push-far ordering.  The to-visit stack lives in LDS.
+// Bvh_intersect (K/bvh.h:47-109), one node per execution, as two voted phases so that a wave does not pay for the
+// triangle code at every step of the walk: bvh_phase visits an inner node (two box tests, near-first / push-far
+// ordering; a lane that finds itself at a leaf only changes to ST_LEAF), leaf_phase tests a leaf's triangles and
+// pops the next node.  The to-visit stack lives in LDS.
+DEV int bvh_finished(const SceneView& S, LaneState& L) {
+    if (L.bvh_which == 0 && !S.actor_bvh_empty && !(L.shadow && L.trace_hit)) {
+        L.bvh_which = 1;
+        L.bvh_cur = 0;
+        L.bvh_top = 0;
+        return ST_BVH;
+    }
+    return ST_SHADE;
+}
+
 DEV int bvh_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
+    const int* __restrict__ bvh = L.bvh_which ? S.actor_bvh : S.world_bvh;
+    const float limit = L.shadow ? L.bvh_dist : L.h.distance;
+    const int second = bvh[L.bvh_cur];
+    if (second <= 0) return ST_LEAF;
+    const int* a = bvh + L.bvh_cur + 7;
+    const int* b = bvh + second;
+    float t1 = box_quick(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
+                         as_float(a[6]), L.o, L.inv);
+    float t2 = box_quick(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
+                         as_float(b[6]), L.o, L.inv);
+    const bool miss1 = (t1 != t1) || t1 > limit;
+    const bool miss2 = (t2 != t2) || t2 > limit;
+    if (miss1) {
+        if (miss2) {
+            if (L.bvh_top == 0) return bvh_finished(S, L);
+            L.bvh_cur = stack.pop(--L.bvh_top);
+        } else {
+            L.bvh_cur = second;
+        }
+    } else if (miss2) {
+        L.bvh_cur += 7;
+    } else if (t1 < t2) {
+        stack.push(L.bvh_top++, second);
+        L.bvh_cur += 7;
+    } else {
+        stack.push(L.bvh_top++, L.bvh_cur + 7);
+        L.bvh_cur = second;
+    }
+    return ST_BVH;
+}
+
+DEV int leaf_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
     const int* __restrict__ bvh = L.bvh_which ? S.actor_bvh : S.world_bvh;
     const int* __restrict__ trigs = S.trigs;
     float limit = L.shadow ? L.bvh_dist : L.h.distance;
-    bool finished = false;
-    const int head = bvh[L.bvh_cur];
-    if (head <= 0) {
-        const int prim = -head;
-        const int n = trigs[prim];
-        for (int i = 0; i < n; i++) {
-            f3 nn;
-            float u, v;
-            int mat;
-            float dist = triangle_hit(trigs + prim + 1 + 20 * i, limit, L.o, L.d, nn, u, v, mat);
-            if (dist == dist) {
-                Hit t = L.h;
-                if (material_sample(S, mat, u, v, t)) {
-                    if (!L.shadow) {
-                        L.h.color = t.color;
-                        L.h.emittance = t.emittance;
-                        L.h.normal = nn;
-                        L.h.distance = dist;
-                    }
-                    limit = dist;
-                    L.trace_hit = true;
+    const int prim = -bvh[L.bvh_cur];
+    const int n = trigs[prim];
+    for (int i = 0; i < n; i++) {
+        f3 nn;
+        float u, v;
+        int mat;
+        float dist = triangle_hit(trigs + prim + 1 + 20 * i, limit, L.o, L.d, nn, u, v, mat);
+        if (dist == dist) {
+            Hit t = L.h;
+            if (material_sample(S, mat, u, v, t)) {
+                if (!L.shadow) {
+                    L.h.color = t.color;
+                    L.h.emittance = t.emittance;
+                    L.h.normal = nn;
+                    L.h.distance = dist;
                 }
+                limit = dist;
+                L.trace_hit = true;
             }
         }
-        if (L.shadow) L.bvh_dist = limit;
-        if ((L.shadow && L.trace_hit) || L.bvh_top == 0)
-            finished = true;
-        else
-            L.bvh_cur = stack.pop(--L.bvh_top);
-    } else {
-        const int second = head;
-        const int* a = bvh + L.bvh_cur + 7;
-        const int* b = bvh + second;
-        float t1 = box_quick(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
-                             as_float(a[6]), L.o, L.inv);
-        float t2 = box_quick(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
-                             as_float(b[6]), L.o, L.inv);
-        const bool miss1 = (t1 != t1) || t1 > limit;
-        const bool miss2 = (t2 != t2) || t2 > limit;
-        if (miss1) {
-            if (miss2) {
-                if (L.bvh_top == 0)
-                    finished = true;
-                else
-                    L.bvh_cur = stack.pop(--L.bvh_top);
-            } else {
-                L.bvh_cur = second;
-            }
-        } else if (miss2) {
-            L.bvh_cur += 7;
-        } else if (t1 < t2) {
-            stack.push(L.bvh_top++, second);
-            L.bvh_cur += 7;
-        } else {
-            stack.push(L.bvh_top++, L.bvh_cur + 7);
-            L.bvh_cur = second;
-        }
     }
-    if (finished) {
-        if (L.bvh_which == 0 && !S.actor_bvh_empty && !(L.shadow && L.trace_hit)) {
-            L.bvh_which = 1;
-            L.bvh_cur = 0;
-            L.bvh_top = 0;
-            return ST_BVH;
-        }
-        return ST_SHADE;
-    }
+    if (L.shadow) L.bvh_dist = limit;
+    if ((L.shadow && L.trace_hit) || L.bvh_top == 0) return bvh_finished(S, L);
+    L.bvh_cur = stack.pop(--L.bvh_top);
     return ST_BVH;
 }
 
@@ -933,8 +935,9 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(Wa
         const int n_march = count_lanes(st == ST_MARCH);
         const int n_block = count_lanes(st == ST_BLOCK);
         const int n_shade = count_lanes(st == ST_SHADE);
-        const int n_bvh = BVH ? __popcll(__ballot(st == ST_BVH)) : 0;
-        if ((n_march | n_block | n_shade | n_bvh) == 0) {
+        const int n_bvh = BVH ? count_lanes(st == ST_BVH) : 0;
+        const int n_leaf = BVH ? count_lanes(st == ST_LEAF) : 0;
+        if ((n_march | n_block | n_shade | n_bvh | n_leaf) == 0) {
             // nobody is tracing: everything is parked, so folding / pixel hand-out can always advance
             if (G == 1 || __ballot(st != ST_DONE) == 0 || ++idle_rounds > 64) break;
             WaveArgPtr A = fresh_args();
@@ -949,21 +952,27 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(Wa
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         int ph;
-        if (BVH && n_bvh > 0 && n_bvh >= n_march && n_bvh >= n_block && n_bvh >= n_shade) {
+        const int n_octree = n_march > n_block ? (n_march > n_shade ? n_march : n_shade) : (n_block > n_shade ? n_block : n_shade);
+        if (BVH && n_bvh > 0 && n_bvh >= n_octree && n_bvh >= n_leaf) {
             ph = 1;  // profiled with BLOCK
             const SceneView S = arg_copy(&fresh_args()->S);
             if (STATS) {
                 if (st == ST_BVH) st = bvh_phase(S, L, stack);
             } else {
-                int nv, nm, nb, ns;  // keep visiting nodes while the BVH walk holds the majority
+                int nv, nl, nm, nb, ns;  // keep visiting nodes while the BVH walk holds the majority
                 do {
                     if (st == ST_BVH) st = bvh_phase(S, L, stack);
                     nv = count_lanes(st == ST_BVH);
+                    nl = count_lanes(st == ST_LEAF);
                     nm = count_lanes(st == ST_MARCH);
                     nb = count_lanes(st == ST_BLOCK);
                     ns = count_lanes(st == ST_SHADE);
-                } while (nv > 0 && nv >= nm && nv >= nb && nv >= ns);
+                } while (nv > 0 && nv >= nl && nv >= nm && nv >= nb && nv >= ns);
             }
+        } else if (BVH && n_leaf > 0 && n_leaf >= n_octree) {
+            ph = 1;
+            const SceneView S = arg_copy(&fresh_args()->S);
+            if (st == ST_LEAF) st = leaf_phase(S, L, stack);
         } else if (n_march * kWMarch >= n_block * kWBlock && n_march * kWMarch >= n_shade * kWShade) {
             ph = 0;
             // the few scalars MARCH needs are re-read here too (scalar cache hits): kept live across
@@ -978,7 +987,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(Wa
                     nm = count_lanes(st == ST_MARCH);
                     nb = count_lanes(st == ST_BLOCK);
                     ns = count_lanes(st == ST_SHADE);
-                    nv = count_lanes(st == ST_BVH || st == ST_TRACED);
+                    nv = count_lanes(st == ST_BVH || st == ST_LEAF || st == ST_TRACED);
                 } while (nm > 0 && nm >= nb && nm >= ns && nm >= nv);
             } else {
                 // stay in the march while it keeps the majority: an inner loop whose back-edge carries
