@@ -980,20 +980,13 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(Wa
             WaveArgPtr A = fresh_args();
             const SceneView Sm = arg_copy(&A->S);
             const RenderOpts Om = arg_copy(&A->O);
-            if (BVH) {
-                int nm, nb, ns, nv;
-                do {
-                    if (st == ST_MARCH) st = march_phase<TREE, END>(Sm, Om, L);
-                    nm = count_lanes(st == ST_MARCH);
-                    nb = count_lanes(st == ST_BLOCK);
-                    ns = count_lanes(st == ST_SHADE);
-                    nv = count_lanes(st == ST_BVH || st == ST_LEAF || st == ST_TRACED);
-                } while (nm > 0 && nm >= nb && nm >= ns && nm >= nv);
-            } else {
+            {
                 // stay in the march while it keeps the majority: an inner loop whose back-edge carries
                 // only what MARCH changes (the outer loop's back-edge re-shuffles ~25 state registers)
                 // The lanes' states stay untouched inside the loop; they are written once when it is left.
-                int nm = n_march, nb = n_block, ns = n_shade;
+                // `ne` counts the lanes waiting where a trace that ends here goes next (SHADE, or the entity BVHs)
+                int nm = n_march, nb = n_block, ne = BVH ? n_bvh + n_leaf : n_shade;
+                const int n_other = BVH ? n_shade : 0;
                 const LaneMask entered = __ballot(st == ST_MARCH);
                 LaneMask marching = entered, to_block = 0;
                 int data, level;
@@ -1005,11 +998,11 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(Wa
                     LaneMask cand, live;
                     march_step<TREE>(Sm, Om, L, marching, cand, live, data, level);
                     nb += __popcll(cand);
-                    ns += __popcll(marching & ~live);
+                    ne += __popcll(marching & ~live);
                     to_block |= cand;
                     marching = live & ~cand;
                     nm = __popcll(marching);
-                } while (nm > 0 && nm * kWMarch >= nb * kWBlock && nm * kWMarch >= ns * kWShade);
+                } while (nm > 0 && nm * kWMarch >= nb * kWBlock && nm * kWMarch >= ne * kWShade && nm >= n_other);
                 const bool found = in_mask(to_block);
                 L.cand_data = found ? data : L.cand_data;
                 L.cand_level = found ? level : L.cand_level;
