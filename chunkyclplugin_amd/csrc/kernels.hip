@@ -291,6 +291,7 @@ struct LaneState {
     // entity BVH traversal (K/bvh.h:22-113): current node, stack height, which BVH (0 world, 1 actor),
     // and the shadow ray's own copy of record.distance
     int bvh_cur, bvh_top, bvh_which;
+    int bvh_head;  // first word of node bvh_cur (> 0: index of its second child; <= 0: -pointer to a leaf's triangles)
     float bvh_dist;
     f3 far;  // per axis 1.0 where the ray runs towards +axis (inv > 0), else 0.0: selects a leaf's exit plane
     // main record
@@ -456,68 +457,65 @@ DEV int claim_slot(WorkQueue Q, PixelPool& pool, bool need) {
 
 // The octree part of a trace is over: continue closestIntersect (K/kernel.h:16-18) in the entity BVHs.
 // A shadow trace only needs the boolean, so it skips the BVHs once anything was hit.
+// The walk keeps the first word of its current node in a register: a visit reads both children whole (their
+// first words with their boxes), so stepping down needs no further read — only a pop does.
+DEV int bvh_enter(const SceneView& S, LaneState& L, int which) {
+    L.bvh_which = which;
+    L.bvh_cur = 0;
+    L.bvh_top = 0;
+    L.bvh_head = (which ? S.actor_bvh : S.world_bvh)[0];
+    return L.bvh_head <= 0 ? ST_LEAF : ST_BVH;
+}
 DEV int bvh_begin(const SceneView& S, LaneState& L) {
     L.trace_hit = L.oct_hit;
     if (L.shadow && L.trace_hit) return ST_SHADE;
-    L.bvh_which = S.world_bvh_empty ? 1 : 0;
     if (S.world_bvh_empty && S.actor_bvh_empty) return ST_SHADE;
-    L.bvh_cur = 0;
-    L.bvh_top = 0;
     L.bvh_dist = L.h.distance;
-    return ST_BVH;
+    return bvh_enter(S, L, S.world_bvh_empty ? 1 : 0);
 }
 
 // Bvh_intersect (K/bvh.h:47-109), one node per execution, as two voted phases so that a wave does not pay for the
 // triangle code at every step of the walk: bvh_phase visits an inner node (two box tests, near-first / push-far
-// ordering; a lane that finds itself at a leaf only changes to ST_LEAF), leaf_phase tests a leaf's triangles and
-// pops the next node.  The to-visit stack lives in LDS.
+// ordering), leaf_phase tests a leaf's triangles; both leave the lane at its next node.  The to-visit stack
+// lives in LDS.
 DEV int bvh_finished(const SceneView& S, LaneState& L) {
-    if (L.bvh_which == 0 && !S.actor_bvh_empty && !(L.shadow && L.trace_hit)) {
-        L.bvh_which = 1;
-        L.bvh_cur = 0;
-        L.bvh_top = 0;
-        return ST_BVH;
-    }
+    if (L.bvh_which == 0 && !S.actor_bvh_empty && !(L.shadow && L.trace_hit)) return bvh_enter(S, L, 1);
     return ST_SHADE;
+}
+DEV int bvh_pop(const SceneView& S, LaneState& L, LdsStack& stack) {
+    if (L.bvh_top == 0) return bvh_finished(S, L);
+    L.bvh_cur = stack.pop(--L.bvh_top);
+    L.bvh_head = (L.bvh_which ? S.actor_bvh : S.world_bvh)[L.bvh_cur];
+    return L.bvh_head <= 0 ? ST_LEAF : ST_BVH;
 }
 
 DEV int bvh_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
     const int* __restrict__ bvh = L.bvh_which ? S.actor_bvh : S.world_bvh;
     const float limit = L.shadow ? L.bvh_dist : L.h.distance;
-    const int second = bvh[L.bvh_cur];
-    if (second <= 0) return ST_LEAF;
-    const int* a = bvh + L.bvh_cur + 7;
+    const int first = L.bvh_cur + 7, second = L.bvh_head;
+    const int* a = bvh + first;
     const int* b = bvh + second;
+    const int head_a = a[0], head_b = b[0];
     float t1 = box_quick(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
                          as_float(a[6]), L.o, L.inv);
     float t2 = box_quick(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
                          as_float(b[6]), L.o, L.inv);
     const bool miss1 = (t1 != t1) || t1 > limit;
     const bool miss2 = (t2 != t2) || t2 > limit;
-    if (miss1) {
-        if (miss2) {
-            if (L.bvh_top == 0) return bvh_finished(S, L);
-            L.bvh_cur = stack.pop(--L.bvh_top);
-        } else {
-            L.bvh_cur = second;
-        }
-    } else if (miss2) {
-        L.bvh_cur += 7;
-    } else if (t1 < t2) {
-        stack.push(L.bvh_top++, second);
-        L.bvh_cur += 7;
-    } else {
-        stack.push(L.bvh_top++, L.bvh_cur + 7);
-        L.bvh_cur = second;
-    }
-    return ST_BVH;
+    if (miss1 & miss2) return bvh_pop(S, L, stack);
+    // near child first; the other one is pushed when both are hit (K/bvh.h:86-103: the first child is the near one
+    // only when t1 < t2)
+    const bool go_first = !miss1 & (miss2 | (t1 < t2));
+    if (!miss1 & !miss2) stack.push(L.bvh_top++, go_first ? second : first);
+    L.bvh_cur = go_first ? first : second;
+    L.bvh_head = go_first ? head_a : head_b;
+    return L.bvh_head <= 0 ? ST_LEAF : ST_BVH;
 }
 
 DEV int leaf_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
-    const int* __restrict__ bvh = L.bvh_which ? S.actor_bvh : S.world_bvh;
     const int* __restrict__ trigs = S.trigs;
     float limit = L.shadow ? L.bvh_dist : L.h.distance;
-    const int prim = -bvh[L.bvh_cur];
+    const int prim = -L.bvh_head;
     const int n = trigs[prim];
     for (int i = 0; i < n; i++) {
         f3 nn;
@@ -539,9 +537,8 @@ DEV int leaf_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
         }
     }
     if (L.shadow) L.bvh_dist = limit;
-    if ((L.shadow && L.trace_hit) || L.bvh_top == 0) return bvh_finished(S, L);
-    L.bvh_cur = stack.pop(--L.bvh_top);
-    return ST_BVH;
+    if (L.shadow && L.trace_hit) return bvh_finished(S, L);
+    return bvh_pop(S, L, stack);
 }
 
 // All launch parameters travel as ONE by-value struct and are read through the kernel-argument
@@ -896,7 +893,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(Wa
     L.radiance = mk3(0, 0, 0);
     L.oct_hit = false;
     L.trace_hit = false;
-    L.bvh_cur = L.bvh_top = L.bvh_which = 0;
+    L.bvh_cur = L.bvh_top = L.bvh_which = L.bvh_head = 0;
     L.bvh_dist = 0;
     // per-group radiance buffers behind the BVH stacks in dynamic LDS
     GroupLds glds{nullptr};
