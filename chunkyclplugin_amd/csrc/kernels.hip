@@ -280,7 +280,6 @@ struct LaneState {
     f3 radiance, throughput, o, d;
     int depth;
     bool shadow;       // the current trace is the sun-sample trace of K/rayTracer.cl:101-106
-    float shadow_emit; // sampleRecord.emittance = |dot(sun dir, normal)|
     // trace
     f3 inv;
     float dist_march;
@@ -296,7 +295,6 @@ struct LaneState {
     f3 far;  // per axis 1.0 where the ray runs towards +axis (inv > 0), else 0.0: selects a leaf's exit plane
     // main record
     Hit h;
-    f3 point;
 };
 
 // (int)floor(x) in one instruction, saturating like v_cvt_i32_f32 (math self test 18).  NaN converts to
@@ -586,15 +584,17 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
     // Each block below appears once, so a shade round issues it once however the lanes split.
     const bool main_trace = !L.shadow;
     if (!hit) {  // intersectSky (K/kernel.h:26-31); record.emittance = 1 for the main ray (K/rayTracer.cl:95)
-        const float e = main_trace ? 1.0f : L.shadow_emit;
+        // a shadow ray's record.emittance is the |dot(sun dir, normal)| stored at its start: nothing writes it during
+        // the shadow trace (the block and triangle tests leave the main record alone for shadow rays)
+        const float e = main_trace ? 1.0f : L.h.emittance;
         L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, e);
         if (main_trace) return ST_NEXT;
     }
     bool bounce = true, to_sun = false;
     if (main_trace) {
-        L.point = L.o + L.d * (L.h.distance - kOffset);
+        // the hit point (K/kernel.h:21-23) becomes the origin of the shadow ray and stays there until the bounce
+        L.o = L.o + L.d * (L.h.distance - kOffset);
         // applyRayColor (K/kernel.h:33-44)
-        L.o = L.point;
         f3 c = mk3(L.h.color.x, L.h.color.y, L.h.color.z);
         L.throughput = L.throughput * c;
         L.radiance = L.radiance + (c * (L.h.emittance * O.emitter_scale)) * L.throughput;
@@ -639,12 +639,10 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
         if (to_sun) {
             L.d = a;
             L.h.emittance = rt_fabs(dot(L.d, n));
-            L.shadow_emit = L.h.emittance;
             L.shadow = true;
         } else {
             const float tx = root * cs, ty = root * sn, tz = rt_sqrt(1 - x1);
             const float vx = a.y * n.z - a.z * n.y, vy = a.z * n.x - a.x * n.z, vz = a.x * n.y - a.y * n.x;
-            L.o = L.point;
             L.d = f3{a.x * tx + vx * ty + n.x * tz, a.y * tx + vy * ty + n.y * tz, a.z * tx + vz * ty + n.z * tz};
             L.o = L.o + L.d * kOffset;
             L.depth += 1;
@@ -877,8 +875,6 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(Wa
     L.h.normal = mk3(0, 0, 0);
     L.h.color = f4{0, 0, 0, 0};
     L.h.emittance = 0;
-    L.point = mk3(0, 0, 0);
-    L.shadow_emit = 0;
     L.cand_data = 0;
     L.cand_level = 0;
     L.pass = 0;
