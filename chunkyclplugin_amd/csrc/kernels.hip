@@ -268,28 +268,34 @@ enum : int {
 };
 
 struct LaneState {
+    // Small fields share registers (bit-fields): at the 96-VGPR budget of five waves per SIMD every register of
+    // path state that is saved is one spill less; none of these is touched by the march loop.
     // pixel / pass
-    int gid, pass;
-    f3 mean;             // G = 1 only (grouped lanes keep the means in LDS)
-    int slot, serial;    // G > 1: which open pixel of the group this lane's pass belongs to, and its serial
-    int cur;             // G > 1, leader: the open pixel passes are issued from
-    int serial_counter;  // G > 1, leader
-    bool exhausted;      // G > 1, leader: the pixel queue is empty
+    int gid;
+    unsigned pass : 8;     // pass index inside the launch (< kMaxPassesPerLaunch)
+    unsigned slot : 1;     // G > 1: which open pixel of the group this lane's pass belongs to,
+    unsigned serial : 23;  //        and that pixel's serial
+    f3 mean;               // G = 1 only (grouped lanes keep the means in LDS)
+    unsigned cur : 1;              // G > 1, leader: the open pixel passes are issued from
+    unsigned exhausted : 1;        // G > 1, leader: the pixel queue is empty
+    unsigned serial_counter : 23;  // G > 1, leader
     unsigned rng;
     // path
     f3 radiance, throughput, o, d;
-    int depth;
-    bool shadow;       // the current trace is the sun-sample trace of K/rayTracer.cl:101-106
+    unsigned depth : 8;
+    unsigned shadow : 1;      // the current trace is the sun-sample trace of K/rayTracer.cl:101-106
+    unsigned oct_hit : 1;
+    unsigned trace_hit : 1;   // closestIntersect result so far (octree, then the BVHs)
+    unsigned cand_level : 4;  // level of the candidate's leaf
+    unsigned bvh_which : 1;   // entity BVH walked: 0 world, 1 actor
     // trace
     f3 inv;
     float dist_march;
     int steps;
-    bool oct_hit;
-    bool trace_hit;  // closestIntersect result so far (octree, then the BVHs)
-    int cand_data, cand_level;
-    // entity BVH traversal (K/bvh.h:22-113): current node, stack height, which BVH (0 world, 1 actor),
+    int cand_data;
+    // entity BVH traversal (K/bvh.h:22-113): current node, stack height,
     // and the shadow ray's own copy of record.distance
-    int bvh_cur, bvh_top, bvh_which;
+    int bvh_cur, bvh_top;
     int bvh_head;  // first word of node bvh_cur (> 0: index of its second child; <= 0: -pointer to a leaf's triangles)
     float bvh_dist;
     f3 far;  // per axis 1.0 where the ray runs towards +axis (inv > 0), else 0.0: selects a leaf's exit plane
