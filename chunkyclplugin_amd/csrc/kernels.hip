@@ -742,7 +742,7 @@ constexpr int kHandoverBatch = CHUNKY_HANDOVER_BATCH;
 constexpr int kWMarch = CHUNKY_W_MARCH, kWBlock = CHUNKY_W_BLOCK, kWShade = CHUNKY_W_SHADE;
 // parked radiances per open pixel (a pass is issued only inside fold + ring): two per lane of the group; the rings
 // of a workgroup take 18 KB of LDS either way, which leaves room for five workgroups per CU
-constexpr int ring_size(int group) { return group >= 16 ? 32 : 16; }
+constexpr int ring_size(int group) { return 2 * group; }
 struct GroupLds {
     float4* rad;  // [2][kRing] {r, g, b, tag}
     int* hdr;     // [2][8]  {gid, fold, issue, serial, mean.x, mean.y, mean.z, -}
@@ -823,7 +823,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
     }
     // ---- hand passes of the issuing pixel to the lanes that are free ----
     const bool want = st == ST_IDLE;
-    const unsigned gmask = (unsigned)(__ballot(want) >> leader) & ((1u << G) - 1u);
+    const unsigned gmask = (unsigned)(__ballot(want) >> leader) & (G >= 32 ? 0xFFFFFFFFu : (1u << (G & 31)) - 1u);
     const int cur = __shfl(L.cur, leader);
     const int exhausted = __shfl((int)L.exhausted, leader);
     const int4 hc = hdr4[2 * cur];
@@ -872,7 +872,10 @@ template <int TREE, bool STATS, int G, bool BVH = false>
 // Five workgroups per CU (96 VGPRs; a march step waits on one or two dependent tree reads, and the fifth wave per
 // SIMD fills that time: +5 % over four); the entity-BVH kernels need ~125 registers and stay at four, like the
 // profiling build (its counters would spill).
-__global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : 5)) render_waves(WaveArgs unused_by_name) {
+#ifndef CHUNKY_WAVES_PER_SIMD
+#define CHUNKY_WAVES_PER_SIMD 5
+#endif
+__global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SIMD)) render_waves(WaveArgs unused_by_name) {
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
     LdsStack stack{lds + threadIdx.x, (int)blockDim.x};
@@ -1262,11 +1265,12 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
                 if (S.wide_bits[i] != 3) tree = -1;
         }
         typedef void (*Kernel)(WaveArgs);
-        // lanes per pixel (see next_sample): 8, or 16 when this GPU owns few pixels (multi-GPU tile
-        // split: measured 6.9x vs 6.5x at 1/8 of a 1080p image); CHUNKY_DEBUG_GROUP=1|8|16 for experiments
+        // lanes per pixel (see next_sample): 8; 16 or 32 when this GPU owns few pixels (multi-GPU tile split: the fewer
+        // pixels per group, the longer the tail of the launch); CHUNKY_DEBUG_GROUP=1|8|16|32 for experiments
         const size_t stack = lds;
-        int group = T.n_local < (1 << 19) ? 16 : 8;
-        if (P.n < 2 * group) group = P.n >= 16 ? 8 : 1;  // a group needs a few passes per lane to stay busy
+        int group = T.n_local < (3 << 17) ? 32 : (T.n_local < (3 << 18) ? 16 : 8);
+        while (group > 8 && P.n < 2 * group) group /= 2;  // a group needs a few passes per lane to stay busy
+        if (P.n < 2 * group) group = 1;
         if (const char* g = getenv("CHUNKY_DEBUG_GROUP")) group = atoi(g);
         switch ((variant >> 4) & 3) {  // variant bits 4-5 force the group size (tests cover all three)
             case 1: group = 1; break;
@@ -1274,9 +1278,10 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
             case 3: group = 16; break;
             default: break;
         }
-        if (group != 1 && group != 8 && group != 16) group = 8;
-        if (group > 1) lds += (size_t)(block / group) * (2 * ring_size(group) * 16 + 64);
+        if (group != 1 && group != 8 && group != 16 && group != 32) group = 8;
         const bool has_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
+        if (group == 32 && (has_bvh || stats)) group = 16;
+        if (group > 1) lds += (size_t)(block / group) * (2 * ring_size(group) * 16 + 64);
         Kernel k;
         if (has_bvh && !stats && group > 1) {
             if (group == 16)
@@ -1297,6 +1302,8 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
                 case 19: k = render_waves<19, false, 1>; break;
                 default: k = render_waves<-1, false, 1>; break;
             }
+        } else if (group == 32) {
+            k = tree == 17 ? render_waves<17, false, 32> : (tree == 18 ? render_waves<18, false, 32> : render_waves<-1, false, 32>);
         } else if (group == 16) {
             k = tree == 17 ? render_waves<17, false, 16> : (tree == 18 ? render_waves<18, false, 16> : render_waves<-1, false, 16>);
         } else {
@@ -1313,9 +1320,10 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
         if (e != hipSuccess) return e;
         int bpc = occ > 0 ? occ : 1;
-        int want = (T.n_local + block - 1) / block;
+        // a pixel keeps `group` lanes busy (one pass each), so that many lanes per pixel are worth launching
+        const long long want = ((long long)T.n_local * group + block - 1) / block;
         int grid = n_cu * bpc;
-        if (grid > want) grid = want;
+        if ((long long)grid > want) grid = (int)want;
         if (grid <= 0 || P.n <= 0) return hipSuccess;
         e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;

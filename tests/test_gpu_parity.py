@@ -185,6 +185,24 @@ def test_launch_chunking_is_invisible(gpu_instance, port):
     loader.close()
 
 
+@pytest.mark.parametrize("group", [1, 8, 16, 32])
+def test_every_group_size_gives_the_same_image(gpu_instance, port, group):
+    """Lanes per pixel (CHUNKY_DEBUG_GROUP forces it) only changes who computes which pass: 64 passes, bit-identical."""
+    import os
+    sc = gs.make("outdoor").with_view(96, 54)
+    seeds = scenes.java_random_ints(64)
+    loader, r = make_renderer(gpu_instance, sc)
+    os.environ["CHUNKY_DEBUG_GROUP"] = str(group)
+    try:
+        r.render_passes(seeds)
+        got = r.read()
+    finally:
+        del os.environ["CHUNKY_DEBUG_GROUP"]
+    assert_radiance(got, port.render_passes(sc, seeds), f"group {group}")
+    r.close()
+    loader.close()
+
+
 def test_edge_cases(gpu_instance, port):
     sc = gs.make("outdoor").with_view(33, 17)          # ragged: not a multiple of the block or tile size
     loader, r = make_renderer(gpu_instance, sc)
