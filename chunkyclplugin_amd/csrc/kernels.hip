@@ -562,6 +562,7 @@ struct WaveArgs {
     unsigned long long* stats;
     unsigned stack_bytes;  // size of the BVH-stack area at the start of dynamic LDS
 };
+static_assert(sizeof(WaveArgs) <= 4096, "launch arguments must fit the 4 KB kernel-argument segment");
 typedef const WaveArgs __attribute__((address_space(4))) * WaveArgPtr;
 
 // copy one member struct out of the argument segment (explicit cast: the host pass has no

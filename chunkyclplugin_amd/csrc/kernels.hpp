@@ -32,7 +32,7 @@ struct HitRecord {
 // Seeds of the passes one launch runs, passed by value in the kernel-argument segment (wave-uniform
 // scalar loads, no per-launch host->device copy): pass k uses seed[k] and bufferSpp first_spp + k
 // (OpenClPathTracingRenderer.java:106-109).
-constexpr int kMaxPassesPerLaunch = 64;
+constexpr int kMaxPassesPerLaunch = 256;  // seeds travel in the kernel-argument segment (4 KB in all); the pass index is 8 bits
 struct PassSeeds {
     int n, first_spp;
     int seed[kMaxPassesPerLaunch];

@@ -168,9 +168,9 @@ def test_render_matches_oracle(gpu_instance, port, name, w, h, passes, first, va
 
 def test_launch_chunking_is_invisible(gpu_instance, port):
     """n passes in one call == n calls of one pass (the reference's one launch per spp), including
-    more passes than one launch carries (64)."""
-    sc = gs.make("outdoor").with_view(64, 40)
-    seeds = scenes.java_random_ints(70)
+    more passes than one launch carries (256)."""
+    sc = gs.make("outdoor").with_view(48, 30)
+    seeds = scenes.java_random_ints(262)
     loader, r = make_renderer(gpu_instance, sc)
     r.render_passes(seeds)
     a = r.read()
@@ -180,7 +180,7 @@ def test_launch_chunking_is_invisible(gpu_instance, port):
     r.sync()
     b = r.read()
     np.testing.assert_array_equal(bits(a), bits(b))
-    assert_radiance(a, port.render_passes(sc, seeds), "70 passes")
+    assert_radiance(a, port.render_passes(sc, seeds), "262 passes")
     r.close()
     loader.close()
 
