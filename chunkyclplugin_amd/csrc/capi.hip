@@ -683,12 +683,12 @@ extern "C" int chunky_render_kernel_time(chunky_render* r, float* total_ms, int*
     return CHUNKY_OK;
 }
 
-extern "C" int chunky_render_phase_stats(chunky_render* r, uint64_t* out12, int reset) {
+extern "C" int chunky_render_phase_stats(chunky_render* r, uint64_t* out24, int reset) {
     LOCK_RENDER(r);
-    if (!out12) return fail(CHUNKY_E_INVALID, "phase_stats: NULL output");
+    if (!out24) return fail(CHUNKY_E_INVALID, "phase_stats: NULL output");
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
-    HIP_TRY(hipMemcpy(out12, (char*)r->work_counter.p + 8, 112, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset((char*)r->work_counter.p + 8, 0, 112));
+    HIP_TRY(hipMemcpy(out24, (char*)r->work_counter.p + 8, 192, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset((char*)r->work_counter.p + 8, 0, 192));
     return CHUNKY_OK;
 }
 

@@ -583,10 +583,30 @@ DEV WaveArgPtr fresh_args() {
     return a;
 }
 
+// Cycle sums of parts of SHADE for the profiling build (chunky_render_phase_stats values 14..23).
+struct PartTimers {
+    unsigned long long t[10];
+    unsigned long long last;
+};
+enum : int { PT_SKY = 0, PT_SAMPLING, PT_SETUP, PT_DEPOSIT, PT_FOLD, PT_OPEN, PT_HANDOUT, PT_NEWSAMPLE };
+template <bool ON>
+DEV void part_begin(PartTimers* pt) {
+    if (ON) pt->last = __builtin_amdgcn_s_memtime();
+}
+template <bool ON>
+DEV void part_end(PartTimers* pt, int which) {  // charges the time since the last begin/end to `which`
+    if (ON) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        pt->t[which] += now - pt->last;
+        pt->last = now;
+    }
+}
+
 // SHADE, part 1: everything from the end of a trace to the start of the next one on the same path.
 // Returns ST_SETUP (a ray is ready to be traced) or ST_NEXT (the path is finished).
-template <int TREE, bool BVH>
-DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsStack& stack) {
+template <int TREE, bool BVH, bool PROF = false>
+DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsStack& stack, PartTimers* pt = nullptr) {
+    part_begin<PROF>(pt);
     const bool hit = BVH ? L.trace_hit : L.oct_hit;  // closestIntersect (K/kernel.h:14-24) is complete
     // Each block below appears once, so a shade round issues it once however the lanes split.
     const bool main_trace = !L.shadow;
@@ -597,6 +617,7 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
         L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, e);
         if (main_trace) return ST_NEXT;
     }
+    part_end<PROF>(pt, PT_SKY);
     bool bounce = true, to_sun = false;
     if (main_trace) {
         // the hit point (K/kernel.h:21-23) becomes the origin of the shadow ray and stays there until the bounce
@@ -657,6 +678,7 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
             if (!(L.depth < O.max_depth)) return ST_NEXT;
         }
     }
+    part_end<PROF>(pt, PT_SAMPLING);
     return ST_SETUP;
 }
 
@@ -750,10 +772,11 @@ struct GroupLds {
 };
 enum : int { H_GID = 0, H_FOLD = 1, H_ISSUE = 2, H_SERIAL = 3, H_MEAN = 4 };
 
-template <int TREE, int G>
+template <int TREE, int G, bool PROF = false>
 DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, WaveArgPtr A, PixelPool& pool,
-                    LaneState& L, GroupLds lds, int st) {
+                    LaneState& L, GroupLds lds, int st, PartTimers* pt = nullptr) {
     constexpr int kRing = ring_size(G);
+    part_begin<PROF>(pt);
     const int first_spp = A->P.first_spp, n_passes = A->P.n;
     float* __restrict__ res = A->res;
     WorkQueue Q = arg_copy(&A->Q);
@@ -767,6 +790,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
             make_float4(L.radiance.x, L.radiance.y, L.radiance.z, __int_as_float((L.serial << 8) | L.pass));
         st = ST_IDLE;  // free for another pass
     }
+    part_end<PROF>(pt, PT_DEPOSIT);
     // ---- fold parked radiances strictly in pass order.  Six lanes of the group work at once: lanes 0-2 take
     //      the R, G, B channel of open pixel 0, lanes 3-5 those of open pixel 1, so the fold code — one exact
     //      division per pass and channel, K/rayTracer.cl:109-112 — is issued once for all six ----
@@ -794,6 +818,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
             }
         }
     }
+    part_end<PROF>(pt, PT_FOLD);
     // ---- leader: open a new pixel when the issuing one is used up and a slot is free ----
     bool need_pixel = false;
     int target = 0;
@@ -822,6 +847,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
             L.cur = target;
         }
     }
+    part_end<PROF>(pt, PT_OPEN);
     // ---- hand passes of the issuing pixel to the lanes that are free ----
     const bool want = st == ST_IDLE;
     const unsigned gmask = (unsigned)(__ballot(want) >> leader) & (G >= 32 ? 0xFFFFFFFFu : (1u << (G & 31)) - 1u);
@@ -847,6 +873,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
         int nx = issue + __popc(gmask);
         hdr4[2 * cur] = make_int4(gid, hc.y, nx < limit ? nx : limit, serial);
     }
+    part_end<PROF>(pt, PT_HANDOUT);
     if (st != ST_START) return st;
     // ---- new sample (K/rayTracer.cl:55-91) ----
     {
@@ -863,6 +890,7 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
     L.depth = 0;
     L.shadow = false;
     L.h.distance = rt_inf();
+    part_end<PROF>(pt, PT_NEWSAMPLE);
     return ST_SETUP;
 }
 
@@ -914,6 +942,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
     }
     unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long hand_cycles = 0, hand_execs = 0;  // the pixel/pass hand-over part of SHADE
+    PartTimers parts{{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0};
     unsigned long long t_begin = 0;
     if (STATS) t_begin = __builtin_amdgcn_s_memtime();
     PixelPool pool{0, 0};
@@ -1024,7 +1053,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
             WaveArgPtr A = fresh_args();
             const SceneView S = arg_copy(&A->S);
             const RenderOpts O = arg_copy(&A->O);
-            if (st == ST_SHADE) st = shade_phase<TREE, BVH>(S, O, L, stack);
+            if (st == ST_SHADE) st = shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
             // G > 1: hand-over rounds cost ~300 instructions; wait until a few finished paths share one
             if (count_lanes(st == ST_NEXT) >= (G == 1 ? 1 : kHandoverBatch)) {
                 unsigned long long th = 0;
@@ -1034,13 +1063,15 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
                 if (G == 1)
                     st = next_sample_single<TREE>(S, C, T, A, pool, L, st, false);
                 else
-                    st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, st);
+                    st = next_sample<TREE, G, STATS>(S, C, T, A, pool, L, glds, st, &parts);
                 if (STATS) {
                     hand_cycles += __builtin_amdgcn_s_memtime() - th;
                     hand_execs += 1;
                 }
             }
+            part_begin<STATS>(&parts);
             if (st == ST_SETUP) st = trace_setup<END>(S, L);
+            part_end<STATS>(&parts, PT_SETUP);
         }
         if (STATS) {
             unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
@@ -1064,6 +1095,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
         atomicAdd(&stats[11], 1ull);
         atomicAdd(&stats[12], hand_execs);
         atomicAdd(&stats[13], hand_cycles);
+        for (int k = 0; k < 10; k++) atomicAdd(&stats[14 + k], parts.t[k]);
     }
 }
 

@@ -183,13 +183,15 @@ class HipPathTracingRenderer:
         return ms.value, n.value
 
     def phase_stats(self, reset: bool = True) -> dict:
-        out = np.zeros(14, np.uint64)
+        out = np.zeros(24, np.uint64)
         check(native.lib().chunky_render_phase_stats(self._h, ptr(out), 1 if reset else 0))
         o = out[:9].reshape(3, 3)
         d = {name: {"execs": int(o[i, 0]), "lanes": int(o[i, 1]), "cycles": int(o[i, 2])}
              for i, name in enumerate(("march", "block", "shade"))}
         d["waves"] = {"life_sum": int(out[9]), "life_max": int(out[10]), "n": int(out[11])}
         d["handover"] = {"execs": int(out[12]), "cycles": int(out[13])}
+        d["parts"] = {name: int(out[14 + i]) for i, name in enumerate(
+            ("sky", "sampling", "trace_setup", "deposit", "fold", "open_pixel", "hand_out", "new_sample"))}
         return d
 
     def preview(self) -> np.ndarray:

@@ -129,8 +129,10 @@ int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches);
  * the phases MARCH, BLOCK, SHADE the number of wave-level executions, the lanes active in them and
  * the shader cycles spent (s_memtime), summed over all waves since the last reset (9 values), then
  * the sum and the maximum of the wave lifetimes and the number of waves (3 values), then the executions
- * and cycles of the pixel/pass hand-over part of SHADE (2 values): 14 values in all. */
-int chunky_render_phase_stats(chunky_render* r, uint64_t* out14, int reset);
+ * and cycles of the pixel/pass hand-over part of SHADE (2 values), then ten cycle sums of parts of SHADE
+ * (sky lookup, direction sampling, trace setup, then the hand-over's deposit, fold, pixel opening, pass hand-out,
+ * new sample; two spare): 24 values in all. */
+int chunky_render_phase_stats(chunky_render* r, uint64_t* out24, int reset);
 
 /* Preview kernel (K/rayTracer.cl:115-217; OpenClPreviewRenderer.java:47-115): width*height ARGB ints. */
 int chunky_render_preview(chunky_render* r, int32_t* argb_out);

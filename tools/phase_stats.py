@@ -31,11 +31,13 @@ st = r.phase_stats()
 samples = sc.width * sc.height * passes // world
 w = st.pop("waves")
 ho = st.pop("handover")
+parts = st.pop("parts")
 tot = sum(v["cycles"] for v in st.values())
 out = {"variant": variant, "launch_ms": ms / n, "Msamples/s": samples / (ms / n) / 1e3}
 for k, v in st.items():
     out[k] = {"execs_per_sample": v["execs"] * 64 / samples, "lanes_per_exec": v["lanes"] / max(v["execs"], 1),
               "cycles_per_exec": v["cycles"] / max(v["execs"], 1), "time_share": v["cycles"] / max(tot, 1)}
 out["handover"] = {"execs_per_sample": ho["execs"] * 64 / samples, "cycles_per_exec": ho["cycles"] / max(ho["execs"], 1), "share_of_total": ho["cycles"] / max(tot, 1)}
+out["parts_share_of_total"] = {k: round(v / max(tot, 1), 4) for k, v in parts.items()}
 out["waves"] = {"n": w["n"], "mean_life_over_max": w["life_sum"] / max(w["n"], 1) / max(w["life_max"], 1)}
 print(json.dumps(out, indent=1))
