@@ -983,10 +983,11 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
         idle_rounds = 0;
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
-        int ph;
+        int ph, n_ph1 = n_block;  // lanes served by a phase profiled as BLOCK (the BVH phases are)
         const int n_octree = n_march > n_block ? (n_march > n_shade ? n_march : n_shade) : (n_block > n_shade ? n_block : n_shade);
         if (BVH && n_bvh > 0 && n_bvh >= n_octree && n_bvh >= n_leaf) {
             ph = 1;  // profiled with BLOCK
+            n_ph1 = n_bvh;
             const SceneView S = arg_copy(&fresh_args()->S);
             if (STATS) {
                 if (st == ST_BVH) st = bvh_phase(S, L, stack);
@@ -1003,6 +1004,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
             }
         } else if (BVH && n_leaf > 0 && n_leaf >= n_octree) {
             ph = 1;
+            n_ph1 = n_leaf;
             const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_LEAF) st = leaf_phase(S, L, stack);
         } else if (n_march * kWMarch >= n_block * kWBlock && n_march * kWMarch >= n_shade * kWShade) {
@@ -1075,7 +1077,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
         }
         if (STATS) {
             unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
-            int n = ph == 0 ? n_march : (ph == 1 ? n_block : n_shade);
+            int n = ph == 0 ? n_march : (ph == 1 ? n_ph1 : n_shade);
 #pragma unroll
             for (int k = 0; k < 3; k++)
                 if (ph == k) {

@@ -15,6 +15,8 @@ kw = {}
 if os.environ.get("CHUNKY_STATS_MODELS") == "0":  # the same world with no slab / plant blocks: BLOCK then runs the cube path only
     kw = dict(aabb_frac=0.0, quad_frac=0.0)
 sc = scenes.cached_outdoor_world(chunks=32, height=256, **kw)
+if os.environ.get("CHUNKY_STATS_SCENE") == "entities":  # BASELINE configs[4]; BLOCK then includes the BVH walk
+    sc = scenes.add_entities(sc, 100000, seed=11, actor_tris=5000, region=((40, 90, 40), (470, 170, 470)))
 loader = HipSceneLoader(RendererInstance.get(0))
 loader.load_packed(sc)
 r = HipPathTracingRenderer(loader, sc.width, sc.height)
