@@ -155,6 +155,24 @@ class _Lib:
         return out
 
 
+class PortOptions:
+    """with PortOptions(port, draw_depth=.., max_depth=.., emitter_scale=..): the C restatement renders with the
+    render-loop constants the HIP library exposes as options; restored to the reference's (256, 5, 13) on exit."""
+
+    def __init__(self, port, draw_depth=256, max_depth=5, emitter_scale=13.0):
+        self.port, self.args = port, (int(draw_depth), int(max_depth), float(emitter_scale))
+
+    def __enter__(self):
+        self.port.lib.port_set_options.argtypes = [C.c_int, C.c_int, C.c_float]
+        self.port.lib.port_set_options.restype = None
+        self.port.lib.port_set_options(*self.args)
+        return self
+
+    def __exit__(self, *exc):
+        self.port.lib.port_set_options(256, 5, 13.0)
+        return False
+
+
 class RefLib(_Lib):
     prefix = "ref"
 

@@ -645,6 +645,17 @@ static void put_hit(OracleHit* h, int hit, const Record* r) {
     h->point[0] = r->point.x; h->point[1] = r->point.y; h->point[2] = r->point.z;
 }
 
+/* The three constants of the render loop (K/rayTracer.cl:94 drawDepth 256, :99 emitter factor 13, :107 ray depth 5).
+ * The HIP library exposes them as options (CHUNKY_OPT_DRAW_DEPTH / _EMITTER_SCALE / _MAX_DEPTH); the checker follows
+ * so that non-default values can be compared too.  Defaults = the reference. */
+static int g_draw_depth = 256, g_max_depth = 5;
+static float g_emitter_scale = 13.0f;
+void port_set_options(int draw_depth, int max_depth, float emitter_scale) {
+    g_draw_depth = draw_depth;
+    g_max_depth = max_depth;
+    g_emitter_scale = emitter_scale;
+}
+
 /* One sample: K/rayTracer.cl:40-107.  Returns pixel.color; optionally records each trace. */
 static v3 trace_sample(const OracleScene* s, const Sun* sun, int seed, int gid, OracleHit* hits, int* n_hits) {
     Path p;
@@ -656,7 +667,7 @@ static v3 trace_sample(const OracleScene* s, const Sun* sun, int seed, int gid, 
     int n = 0;
     COUNT(samples, 1);
     do {
-        int hit = closest_intersect(s, &p, &rec, 256);
+        int hit = closest_intersect(s, &p, &rec, g_draw_depth);
         if (hits) put_hit(&hits[n++], hit, &rec);
         if (!hit) {
             rec.emittance = 1;
@@ -664,15 +675,15 @@ static v3 trace_sample(const OracleScene* s, const Sun* sun, int seed, int gid, 
             break;
         }
         COUNT(hits, 1);
-        apply_ray_color(&p, &rec, 13.0f);
+        apply_ray_color(&p, &rec, g_emitter_scale);
         if (sun_sample_direction(sun, &p, &rec, &state)) {
             Record shadow = rec; /* IntersectionRecord_copy, wavefront.h:64-78 */
             shadow.point = rec.normal; /* the copy's dead `point = normal` (wavefront.h:73) */
-            int sh = closest_intersect(s, &p, &shadow, 256);
+            int sh = closest_intersect(s, &p, &shadow, g_draw_depth);
             if (hits) put_hit(&hits[n++], sh, &shadow);
             if (!sh) intersect_sky(s, sun, &p, &shadow);
         }
-    } while (next_path(&p, &rec, &state, 5));
+    } while (next_path(&p, &rec, &state, g_max_depth));
     if (n_hits) *n_hits = n;
     return p.color;
 }

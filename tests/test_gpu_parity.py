@@ -203,6 +203,28 @@ def test_every_group_size_gives_the_same_image(gpu_instance, port, group):
     loader.close()
 
 
+@pytest.mark.parametrize("name,draw,depth,scale", [("outdoor", 24, 3, 13.0), ("indoor", 256, 2, 2.5), ("indoor_sun", 256, 5, 0.0),
+                                                  ("entities", 40, 4, 7.0)])
+def test_render_loop_options_match_oracle(gpu_instance, port, name, draw, depth, scale):
+    """CHUNKY_OPT_DRAW_DEPTH / _MAX_DEPTH / _EMITTER_SCALE (the constants 256 / 5 / 13 of K/rayTracer.cl:94-107; a scale
+    of 0 is Chunky's "emitters off") against the C restatement run with the same values."""
+    from oracle.binding import PortOptions
+    sc = gs.make(name).with_view(96, 60)
+    seeds = scenes.java_random_ints(3)
+    loader, r = make_renderer(gpu_instance, sc)
+    r.set_option(native.OPT_DRAW_DEPTH, draw)
+    r.set_option(native.OPT_MAX_DEPTH, depth)
+    r.set_option(native.OPT_EMITTER_SCALE, scale)
+    r.render_passes(seeds)
+    got = r.read()
+    with PortOptions(port, draw, depth, scale):
+        want = port.render_passes(sc, seeds)
+    assert_radiance(got, want, f"{name} draw {draw} depth {depth} scale {scale}")
+    assert not np.array_equal(bits(want), bits(port.render_passes(sc, seeds))), "the options changed nothing"
+    r.close()
+    loader.close()
+
+
 def test_edge_cases(gpu_instance, port):
     sc = gs.make("outdoor").with_view(33, 17)          # ragged: not a multiple of the block or tile size
     loader, r = make_renderer(gpu_instance, sc)
