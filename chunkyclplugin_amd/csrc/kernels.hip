@@ -267,6 +267,13 @@ enum : int {
     ST_START = 8   // begin the sample L.pass
 };
 
+// What the leader lane of a pixel group keeps for its group (G > 1) — a property of the lane, not of a path.
+struct GroupCtl {
+    unsigned cur : 1;              // the open pixel passes are issued from
+    unsigned exhausted : 1;        // the pixel queue is empty
+    unsigned serial_counter : 23;  // serial of the last pixel opened
+};
+
 struct LaneState {
     // Small fields share registers (bit-fields): at the 96-VGPR budget of five waves per SIMD every register of
     // path state that is saved is one spill less; none of these is touched by the march loop.
@@ -276,9 +283,6 @@ struct LaneState {
     unsigned slot : 1;     // G > 1: which open pixel of the group this lane's pass belongs to,
     unsigned serial : 23;  //        and that pixel's serial
     f3 mean;               // G = 1 only (grouped lanes keep the means in LDS)
-    unsigned cur : 1;              // G > 1, leader: the open pixel passes are issued from
-    unsigned exhausted : 1;        // G > 1, leader: the pixel queue is empty
-    unsigned serial_counter : 23;  // G > 1, leader
     unsigned rng;
     // path
     f3 radiance, throughput, o, d;
@@ -772,10 +776,10 @@ struct GroupLds {
 };
 enum : int { H_GID = 0, H_FOLD = 1, H_ISSUE = 2, H_SERIAL = 3, H_MEAN = 4 };
 
-template <int TREE, int G, bool PROF = false>
+template <int TREE, int G, bool PROF = false, int RING = ring_size(G)>
 DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T, WaveArgPtr A, PixelPool& pool,
-                    LaneState& L, GroupLds lds, int st, PartTimers* pt = nullptr) {
-    constexpr int kRing = ring_size(G);
+                    LaneState& L, GroupCtl& ctl, GroupLds lds, int st, PartTimers* pt = nullptr) {
+    constexpr int kRing = RING;
     part_begin<PROF>(pt);
     const int first_spp = A->P.first_spp, n_passes = A->P.n;
     float* __restrict__ res = A->res;
@@ -822,15 +826,15 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
     // ---- leader: open a new pixel when the issuing one is used up and a slot is free ----
     bool need_pixel = false;
     int target = 0;
-    if (is_leader && !L.exhausted) {
-        const int4 hc = hdr4[2 * L.cur], ho = hdr4[2 * (L.cur ^ 1)];
+    if (is_leader && !ctl.exhausted) {
+        const int4 hc = hdr4[2 * ctl.cur], ho = hdr4[2 * (ctl.cur ^ 1)];
         const bool cur_open = hc.x >= 0;
         if (!cur_open) {
             need_pixel = true;
-            target = L.cur;
+            target = ctl.cur;
         } else if (hc.z >= n_passes && ho.x < 0) {
             need_pixel = true;
-            target = L.cur ^ 1;
+            target = ctl.cur ^ 1;
         }
     }
     const int pos = claim_slot<(64 / G)>(Q, pool, need_pixel);  // small batches: pixels cannot move between waves once claimed
@@ -838,21 +842,21 @@ DEV int next_sample(const SceneView& S, const CameraView& C, const ShardView& T,
         int gid = pos < T.n_local ? shard_gid(T, pos) : -1;
         if (gid >= C.width * C.height) gid = -1;  // padding of the last tile: only padding follows
         if (gid < 0) {
-            L.exhausted = true;
+            ctl.exhausted = true;
         } else {
             const float* px = res + 3 * (size_t)gid;
-            L.serial_counter += 1;
-            hdr4[2 * target] = make_int4(gid, 0, 0, L.serial_counter);
+            ctl.serial_counter += 1;
+            hdr4[2 * target] = make_int4(gid, 0, 0, ctl.serial_counter);
             hdr4[2 * target + 1] = make_int4(__float_as_int(px[0]), __float_as_int(px[1]), __float_as_int(px[2]), 0);
-            L.cur = target;
+            ctl.cur = target;
         }
     }
     part_end<PROF>(pt, PT_OPEN);
     // ---- hand passes of the issuing pixel to the lanes that are free ----
     const bool want = st == ST_IDLE;
     const unsigned gmask = (unsigned)(__ballot(want) >> leader) & (G >= 32 ? 0xFFFFFFFFu : (1u << (G & 31)) - 1u);
-    const int cur = __shfl(L.cur, leader);
-    const int exhausted = __shfl((int)L.exhausted, leader);
+    const int cur = __shfl(ctl.cur, leader);
+    const int exhausted = __shfl((int)ctl.exhausted, leader);
     const int4 hc = hdr4[2 * cur];
     const int gid = hc.x, issue = hc.z, serial = hc.w;
     int limit = hc.y + kRing;  // ring capacity
@@ -920,9 +924,10 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
     L.mean = mk3(0, 0, 0);
     L.slot = 0;
     L.serial = 0;
-    L.cur = 0;
-    L.serial_counter = 0;
-    L.exhausted = false;
+    GroupCtl ctl;
+    ctl.cur = 0;
+    ctl.serial_counter = 0;
+    ctl.exhausted = false;
     L.steps = 0;
     L.radiance = mk3(0, 0, 0);
     L.oct_hit = false;
@@ -955,7 +960,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
         if (G == 1)
             st = next_sample_single<TREE>(S, C, T, A, pool, L, ST_NEXT, true);
         else
-            st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, ST_IDLE);
+            st = next_sample<TREE, G>(S, C, T, A, pool, L, ctl, glds, ST_IDLE);
         if (st == ST_SETUP) st = trace_setup<END>(S, L);
     }
     int idle_rounds = 0;
@@ -976,7 +981,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
             const SceneView S = arg_copy(&A->S);
             const CameraView C = arg_copy(&A->C);
             const ShardView T = arg_copy(&A->T);
-            st = next_sample<TREE, G>(S, C, T, A, pool, L, glds, st);
+            st = next_sample<TREE, G>(S, C, T, A, pool, L, ctl, glds, st);
             if (st == ST_SETUP) st = trace_setup<END>(S, L);
             continue;
         }
@@ -1065,7 +1070,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
                 if (G == 1)
                     st = next_sample_single<TREE>(S, C, T, A, pool, L, st, false);
                 else
-                    st = next_sample<TREE, G, STATS>(S, C, T, A, pool, L, glds, st, &parts);
+                    st = next_sample<TREE, G, STATS>(S, C, T, A, pool, L, ctl, glds, st, &parts);
                 if (STATS) {
                     hand_cycles += __builtin_amdgcn_s_memtime() - th;
                     hand_execs += 1;
