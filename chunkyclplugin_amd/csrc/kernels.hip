@@ -299,7 +299,9 @@ struct LaneState {
     int cand_data;
     // entity BVH traversal (K/bvh.h:22-113): current node, stack height,
     // and the shadow ray's own copy of record.distance
-    int bvh_cur, bvh_top;
+    int bvh_cur;
+    int bvh_top;             // stack height times the stack's lane stride (= offset of the next free entry)
+    const int* bvh_base;     // the BVH being walked (world or actor)
     int bvh_head;  // first word of node bvh_cur (> 0: index of its second child; <= 0: -pointer to a leaf's triangles)
     float bvh_dist;
     f3 far;  // per axis 1.0 where the ray runs towards +axis (inv > 0), else 0.0: selects a leaf's exit plane
@@ -469,9 +471,10 @@ DEV int claim_slot(WorkQueue Q, PixelPool& pool, bool need) {
 // first words with their boxes), so stepping down needs no further read — only a pop does.
 DEV int bvh_enter(const SceneView& S, LaneState& L, int which) {
     L.bvh_which = which;
+    L.bvh_base = which ? S.actor_bvh : S.world_bvh;
     L.bvh_cur = 0;
     L.bvh_top = 0;
-    L.bvh_head = (which ? S.actor_bvh : S.world_bvh)[0];
+    L.bvh_head = L.bvh_base[0];
     return L.bvh_head <= 0 ? ST_LEAF : ST_BVH;
 }
 DEV int bvh_begin(const SceneView& S, LaneState& L) {
@@ -492,13 +495,14 @@ DEV int bvh_finished(const SceneView& S, LaneState& L) {
 }
 DEV int bvh_pop(const SceneView& S, LaneState& L, LdsStack& stack) {
     if (L.bvh_top == 0) return bvh_finished(S, L);
-    L.bvh_cur = stack.pop(--L.bvh_top);
-    L.bvh_head = (L.bvh_which ? S.actor_bvh : S.world_bvh)[L.bvh_cur];
+    L.bvh_top -= stack.stride;
+    L.bvh_cur = stack.base[L.bvh_top];
+    L.bvh_head = L.bvh_base[L.bvh_cur];
     return L.bvh_head <= 0 ? ST_LEAF : ST_BVH;
 }
 
 DEV int bvh_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
-    const int* __restrict__ bvh = L.bvh_which ? S.actor_bvh : S.world_bvh;
+    const int* __restrict__ bvh = L.bvh_base;
     const float limit = L.shadow ? L.bvh_dist : L.h.distance;
     const int first = L.bvh_cur + 7, second = L.bvh_head;
     const int* a = bvh + first;
@@ -514,7 +518,10 @@ DEV int bvh_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
     // near child first; the other one is pushed when both are hit (K/bvh.h:86-103: the first child is the near one
     // only when t1 < t2)
     const bool go_first = !miss1 & (miss2 | (t1 < t2));
-    if (!miss1 & !miss2) stack.push(L.bvh_top++, go_first ? second : first);
+    if (!miss1 & !miss2) {
+        stack.base[L.bvh_top] = go_first ? second : first;
+        L.bvh_top += stack.stride;
+    }
     L.bvh_cur = go_first ? first : second;
     L.bvh_head = go_first ? head_a : head_b;
     return L.bvh_head <= 0 ? ST_LEAF : ST_BVH;
@@ -933,6 +940,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
     L.oct_hit = false;
     L.trace_hit = false;
     L.bvh_cur = L.bvh_top = L.bvh_which = L.bvh_head = 0;
+    L.bvh_base = nullptr;
     L.bvh_dist = 0;
     // per-group radiance buffers behind the BVH stacks in dynamic LDS
     GroupLds glds{nullptr};
@@ -997,15 +1005,14 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
             if (STATS) {
                 if (st == ST_BVH) st = bvh_phase(S, L, stack);
             } else {
-                int nv, nl, nm, nb, ns;  // keep visiting nodes while the BVH walk holds the majority
+                // keep visiting nodes while the BVH walk holds the majority; a walk only leaves to LEAF or SHADE
+                int nv, nl, ns;
                 do {
                     if (st == ST_BVH) st = bvh_phase(S, L, stack);
                     nv = count_lanes(st == ST_BVH);
                     nl = count_lanes(st == ST_LEAF);
-                    nm = count_lanes(st == ST_MARCH);
-                    nb = count_lanes(st == ST_BLOCK);
                     ns = count_lanes(st == ST_SHADE);
-                } while (nv > 0 && nv >= nl && nv >= nm && nv >= nb && nv >= ns);
+                } while (nv > 0 && nv >= nl && nv >= n_march && nv >= n_block && nv >= ns);
             }
         } else if (BVH && n_leaf > 0 && n_leaf >= n_octree) {
             ph = 1;
