@@ -214,8 +214,25 @@ RT_FN void rt_mirror_linear(float s, int w, int* i0, int* i1, float* a) {
 
 /* ---- pow (the tone-map kernel, reference tonemap/include/post_processing_filter.cl:24-44) --------
  * OpenCL bounds pow at 16 ULP; this definition is x^y = 2^(y*log2|x|) evaluated in binary64 from
- * + - * fma (and one binary32 division) only and rounded once to binary32 (<= 0.51 ULP), with C99's special
- * cases.  These operations are IEEE-exact on x86-64 and gfx950 alike, so host and device agree bit for bit. */
+ * + - * fma and three 32-entry tables, rounded once to binary32 (<= 0.51 ULP), with C99's special
+ * cases.  These operations are IEEE-exact on x86-64 and gfx950 alike, so host and device agree bit for bit.
+ *   log2 x = e + logc[i] + log2(1 + r),  r = m*invc[i] - 1,  i = top five mantissa bits, |r| <= 1/64 (degree 6)
+ *   2^t    = 2^q * exp2tab[j] * 2^f,     t = q + j/32 + f,   |f| <= 1/64 (degree 4)
+ * Tables: csrc/rt_pow_tables.inc (tools/gen_pow_tables.py; hexadecimal literals). */
+#include "rt_pow_tables.inc"
+#if defined(__HIPCC__)
+__device__ __constant__ static const double rt_pow_invc_dev[32] = {RT_POW_INVC};
+__device__ __constant__ static const double rt_pow_logc_dev[32] = {RT_POW_LOGC};
+__device__ __constant__ static const double rt_pow_exp2_dev[32] = {RT_POW_EXP2};
+#endif
+static const double rt_pow_invc_host[32] = {RT_POW_INVC};
+static const double rt_pow_logc_host[32] = {RT_POW_LOGC};
+static const double rt_pow_exp2_host[32] = {RT_POW_EXP2};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_POW_TAB(name, i) rt_pow_##name##_dev[i]
+#else
+#define RT_POW_TAB(name, i) rt_pow_##name##_host[i]
+#endif
 /* A binary64 constant of a polynomial: on the device it is pinned to a scalar register pair, so that each Horner
  * step is one v_fma_f64 with a scalar addend instead of a 64-bit register copy plus v_fmac_f64 (the constants
  * cannot be literals of a VOP3 instruction).  Same value either way. */
@@ -226,70 +243,64 @@ RT_FN double rt_kd(double c) { return c; }
 #endif
 RT_FN unsigned long long rt_d2u(double d) { unsigned long long u; __builtin_memcpy(&u, &d, 8); return u; }
 RT_FN double rt_u2d(unsigned long long u) { double d; __builtin_memcpy(&d, &u, 8); return d; }
-/* log2 of a positive, finite, normal double, to about 2^-38 relative (the result feeds a binary32) */
+/* log2 of a positive, finite, normal double, to about 2^-44 absolute */
 RT_FN double rt_log2_d(double x) {
     const unsigned long long u = rt_d2u(x);
-    int e = (int)((u >> 52) & 0x7ffu) - 1023;
-    double m = rt_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1, 2) */
-    if (m > 1.4142135623730951) {
-        m *= 0.5;
-        e += 1;
-    }
-    /* ln m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716.  1/(m+1): a binary32 quotient (exactly rounded on both
-     * sides) refined by one Newton step in binary64 -> 2^-46; a binary64 division costs three times as much on
-     * the GPU and its last bits are not needed. */
-    const double d = m + 1.0;
-    const double r0 = (double)(1.0f / (float)d);
-    const double r = r0 * __builtin_fma(-d, r0, 2.0);
-    const double s = (m - 1.0) * r, z = s * s;
-    /* odd series to s^15 (next term z^8/17 < 2^-44) */
-    double p = rt_kd(1.0 / 15.0);
-    p = __builtin_fma(p, z, rt_kd(1.0 / 13.0));
-    p = __builtin_fma(p, z, rt_kd(1.0 / 11.0));
-    p = __builtin_fma(p, z, rt_kd(1.0 / 9.0));
-    p = __builtin_fma(p, z, rt_kd(1.0 / 7.0));
-    p = __builtin_fma(p, z, rt_kd(1.0 / 5.0));
-    p = __builtin_fma(p, z, rt_kd(1.0 / 3.0));
-    p = __builtin_fma(p, z, rt_kd(1.0));
-    return __builtin_fma((2.0 * s) * p, 1.4426950408889634 /* 1/ln 2 */, (double)e);
+    const int e = (int)((u >> 52) & 0x7ffu) - 1023;
+    const int i = (int)((u >> 47) & 31u);
+    const double m = rt_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); /* [1, 2) */
+    const double r = __builtin_fma(m, RT_POW_TAB(invc, i), -1.0);
+    /* log2(1 + r) = r (1/ln2) (1 - r/2 + r^2/3 - r^3/4 + r^4/5 - r^5/6) */
+    double p = rt_kd(-1.4426950408889634 / 6.0);
+    p = __builtin_fma(p, r, rt_kd(1.4426950408889634 / 5.0));
+    p = __builtin_fma(p, r, rt_kd(-1.4426950408889634 / 4.0));
+    p = __builtin_fma(p, r, rt_kd(1.4426950408889634 / 3.0));
+    p = __builtin_fma(p, r, rt_kd(-1.4426950408889634 / 2.0));
+    p = __builtin_fma(p, r, rt_kd(1.4426950408889634));
+    return __builtin_fma(p, r, (double)e + RT_POW_TAB(logc, i));
 }
-/* 2^t for |t| <= 200, to about 2^-40 relative */
+/* 2^t for |t| <= 200, to about 2^-39 relative */
 RT_FN double rt_exp2_d(double t) {
-    const double n = __builtin_rint(t);
-    const double f = (t - n) * 0.6931471805599453; /* |f| <= 0.3466; Taylor to f^10 (next term < 2^-42) */
-    double p = rt_kd(1.0 / 3628800.0);
-    p = __builtin_fma(p, f, rt_kd(1.0 / 362880.0));
-    p = __builtin_fma(p, f, rt_kd(1.0 / 40320.0));
-    p = __builtin_fma(p, f, rt_kd(1.0 / 5040.0));
-    p = __builtin_fma(p, f, rt_kd(1.0 / 720.0));
-    p = __builtin_fma(p, f, rt_kd(1.0 / 120.0));
-    p = __builtin_fma(p, f, rt_kd(1.0 / 24.0));
-    p = __builtin_fma(p, f, rt_kd(1.0 / 6.0));
-    p = __builtin_fma(p, f, rt_kd(0.5));
-    p = __builtin_fma(p, f, rt_kd(1.0));
-    p = __builtin_fma(p, f, rt_kd(1.0));
-    return p * rt_u2d((unsigned long long)((int)n + 1023) << 52);
+    const double k = __builtin_rint(t * 32.0);
+    const double f = __builtin_fma(k, -0.03125, t); /* exact; |f| <= 1/64 */
+    const int ki = (int)k;
+    /* 2^f = 1 + f ln2 (1 + f ln2/2 (1 + f ln2/3 (1 + f ln2/4))) expanded */
+    double p = rt_kd(0.009618129107628477);   /* ln2^4 / 24 */
+    p = __builtin_fma(p, f, rt_kd(0.05550410866482158));  /* ln2^3 / 6 */
+    p = __builtin_fma(p, f, rt_kd(0.2402265069591007));   /* ln2^2 / 2 */
+    p = __builtin_fma(p, f, rt_kd(0.6931471805599453));   /* ln2 */
+    p = __builtin_fma(p, f, 1.0);
+    const double scale = rt_u2d((unsigned long long)((ki >> 5) + 1023) << 52);
+    return (p * RT_POW_TAB(exp2, ki & 31)) * scale;
 }
+/* Written without branches (every rule is a select, the later ones override the earlier ones): the three
+ * channels of a pixel then run as independent instruction streams whose table reads overlap. */
 RT_FN float rt_pow(float x, float y) {
-    if (y == 0.0f || x == 1.0f) return 1.0f;
-    if (x != x || y != y) return rt_nan();
     const float ax = rt_fabs(x), ay = rt_fabs(y);
-    if (ay == rt_inf()) {
-        if (ax == 1.0f) return 1.0f;
-        return ((ax < 1.0f) == (y < 0.0f)) ? rt_inf() : 0.0f;
-    }
-    const int y_int = rt_trunc(y) == y;
-    const int y_odd = y_int && ay < 16777216.0f && (((int)ay) & 1);
     const int neg = (int)(rt_f2u(x) >> 31);
-    if (ax == 0.0f || ax == rt_inf()) {
-        const float r = ((ax == 0.0f) == (y < 0.0f)) ? rt_inf() : 0.0f;
-        return (neg && y_odd) ? -r : r;
-    }
-    if (neg && !y_int) return rt_nan();
-    double t = (double)y * rt_log2_d((double)ax);
+    const int y_int = rt_trunc(y) == y;
+    const int y_odd = y_int && ay < 16777216.0f && (((int)(ay < 16777216.0f ? ay : 0.0f)) & 1);
+    const int ax_plain = ax > 0.0f && ax < rt_inf(); /* not 0, inf or NaN */
+    double t = (double)y * rt_log2_d((double)(ax_plain ? ax : 1.0f));
     t = t > 200.0 ? 200.0 : (t < -200.0 ? -200.0 : t);
-    const float r = (float)rt_exp2_d(t);
-    return (neg && y_odd) ? -r : r;
+    t = t == t ? t : 0.0; /* y NaN */
+    float r = (float)rt_exp2_d(t);
+    r = (neg && y_odd) ? -r : r;
+    /* a negative base with a non-integer exponent */
+    r = (neg && !y_int) ? rt_nan() : r;
+    /* x = +-0 or +-inf */
+    {
+        const float z = ((ax == 0.0f) == (y < 0.0f)) ? rt_inf() : 0.0f;
+        r = ax_plain ? r : ((neg && y_odd) ? -z : z);
+    }
+    /* y = +-inf */
+    {
+        const float z = ax == 1.0f ? 1.0f : (((ax < 1.0f) == (y < 0.0f)) ? rt_inf() : 0.0f);
+        r = ay == rt_inf() ? z : r;
+    }
+    r = (x != x || y != y) ? rt_nan() : r;
+    r = (y == 0.0f || x == 1.0f) ? 1.0f : r;
+    return r;
 }
 
 /* PCG hash (reference randomness.h:6-11) — 32-bit wraparound arithmetic. */
