@@ -1217,36 +1217,55 @@ DEV unsigned filter_to_uint(float f) {  // (uint) of color_to_argb (rgba.h:9-14)
     return (unsigned)f;
 }
 
-DEV float filter_channel(float c, int type) {
-    switch (type) {
-        case 0:  // GAMMA
-            return rt_pow(c, (float)(1.0 / 2.2));
-        case 1:  // TONEMAP1
-            c = rt_fmax(0.0f, c - 0.004f);
-            return (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
-        case 2:  // ACES
-            c = (c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f);
-            c = rt_clamp(c, 0.0f, 1.0f);
-            return rt_pow(c, (float)(1.0 / 2.2));
-        case 3: {  // HABLE
-            c *= 16.0f;
-            c = ((c * (0.15f * c + 0.10f * 0.50f) + 0.20f * 0.02f) / (c * (0.15f * c + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f;
-            const float white = ((11.2f * (0.15f * 11.2f + 0.10f * 0.50f) + 0.20f * 0.02f) / (11.2f * (0.15f * 11.2f + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f;
-            return c / white;
-        }
-        default: return c;  // the reference's switch has no default: exposure only
-    }
+DEV float filter_tonemap1(float c) {
+    c = rt_fmax(0.0f, c - 0.004f);
+    return (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
 }
-
-DEV unsigned filter_pixel(float r, float g, float b, float exposure, int type) {
-    r = filter_channel(r * exposure, type);
-    g = filter_channel(g * exposure, type);
-    b = filter_channel(b * exposure, type);
+DEV float filter_aces(float c) {
+    c = (c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f);
+    return rt_clamp(c, 0.0f, 1.0f);
+}
+DEV float filter_hable(float c) {
+    c *= 16.0f;
+    c = ((c * (0.15f * c + 0.10f * 0.50f) + 0.20f * 0.02f) / (c * (0.15f * c + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f;
+    const float white = ((11.2f * (0.15f * 11.2f + 0.10f * 0.50f) + 0.20f * 0.02f) / (11.2f * (0.15f * 11.2f + 0.50f) + 0.20f * 0.30f)) - 0.02f / 0.30f;
+    return c / white;
+}
+DEV unsigned filter_pack(float r, float g, float b) {
     unsigned ur = filter_to_uint(r * 255.0f + 0.5f), ug = filter_to_uint(g * 255.0f + 0.5f), ub = filter_to_uint(b * 255.0f + 0.5f);
     ur = ur > 255u ? 255u : ur;
     ug = ug > 255u ? 255u : ug;
     ub = ub > 255u ? 255u : ub;
     return 0xFF000000u | (ur << 16) | (ug << 8) | ub;  // alpha: (uint)(1 * 255 + 0.5) = 255
+}
+
+// The curve of K's switch (post_processing_filter.cl:23-45) applied to the N channel values of a lane at once: the
+// switch is taken once, and inside a case the N evaluations are independent instruction streams in one basic
+// block, so the long dependent chain of each rt_pow overlaps with the others'.
+template <int N>
+DEV void filter_curve(float (&c)[N], float exposure, int type) {
+#pragma unroll
+    for (int i = 0; i < N; i++) c[i] *= exposure;
+    const float gamma = (float)(1.0 / 2.2);
+    switch (type) {
+        case 0:  // GAMMA
+#pragma unroll
+            for (int i = 0; i < N; i++) c[i] = rt_pow(c[i], gamma);
+            break;
+        case 1:  // TONEMAP1
+#pragma unroll
+            for (int i = 0; i < N; i++) c[i] = filter_tonemap1(c[i]);
+            break;
+        case 2:  // ACES
+#pragma unroll
+            for (int i = 0; i < N; i++) c[i] = rt_pow(filter_aces(c[i]), gamma);
+            break;
+        case 3:  // HABLE
+#pragma unroll
+            for (int i = 0; i < N; i++) c[i] = filter_hable(c[i]);
+            break;
+        default: break;  // the reference's switch has no default: exposure only
+    }
 }
 
 __global__ __launch_bounds__(256) void filter_kernel(long long n, float exposure, const double* __restrict__ in,
@@ -1268,10 +1287,18 @@ __global__ __launch_bounds__(256) void filter_kernel(long long n, float exposure
             for (int k = t; k < 3 * kFilterTile; k += 256) stage[k] = first + k < total ? (float)in[first + k] : 0.0f;
         }
         __syncthreads();
+        float c[6];  // the three channels of this lane's two pixels (a pixel beyond n computes on zeros, stores nothing)
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int px = t + 256 * k;
-            if (base + px < n) out[base + px] = filter_pixel(stage[3 * px], stage[3 * px + 1], stage[3 * px + 2], exposure, type);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) c[3 * k + ch] = stage[3 * px + ch];
+        }
+        filter_curve<6>(c, exposure, type);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int px = t + 256 * k;
+            if (base + px < n) out[base + px] = filter_pack(c[3 * k], c[3 * k + 1], c[3 * k + 2]);
         }
         __syncthreads();
     }
