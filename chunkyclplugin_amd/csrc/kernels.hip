@@ -1,5 +1,8 @@
 // kernels.hip — gfx950 kernels of the Chunky path tracer and their launchers.
 //
+// render_waves (the default): a persistent grid whose waves run the path state machine phase by phase, voted per
+// wave (MARCH / BLOCK / SHADE, plus BVH / LEAF for scenes with entities), with pixels shared by groups of lanes;
+// DESIGN.md section 5 describes it.  filter_kernel: the tone-map kernel of tonemap/include/post_processing_filter.cl.
 // render_lanes: one lane owns one pixel for all the passes of a launch (the running mean of
 // K/rayTracer.cl:109-112 stays in registers: 1 framebuffer read + 1 write per launch instead of per
 // pass, same float recurrence in the same order), walking the path of K/rayTracer.cl:93-107.
@@ -262,7 +265,6 @@ enum : int {
     ST_DONE = 3,   // no pixels left for this lane's group
     ST_NEXT = 4,   // path finished, radiance ready
     ST_SETUP = 5,  // ray ready, trace_setup pending
-    ST_HOLD = 6,   // (unused)
     ST_IDLE = 7,   // lane is free and waits for a pass of its group's pixel
     ST_START = 8   // begin the sample L.pass
 };
@@ -391,19 +393,6 @@ DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneM
     L.steps = advance ? L.steps + 1 : L.steps;
     cand_out = cand;
     live_out = live;
-}
-
-// The same step for the lanes that call it (inside a branch on the lane's state): returns the next state.
-template <int TREE, int END>
-DEV int march_phase(const SceneView& S, const RenderOpts& O, LaneState& L) {
-    const LaneMask here = __ballot(true);
-    LaneMask cand, live;
-    int data, level;
-    march_step<TREE>(S, O, L, here, cand, live, data, level);
-    const bool c = in_mask(cand);
-    L.cand_data = c ? data : L.cand_data;
-    L.cand_level = c ? level : L.cand_level;
-    return c ? ST_BLOCK : (in_mask(here & ~live) ? END : ST_MARCH);
 }
 
 template <int TREE, int END>
