@@ -38,7 +38,7 @@ public class HipPathTracingRenderer implements Renderer {
         sceneLoader.ensureLoad(scene);                                       // :64
         long render = HipNative.renderCreate(ctx, sceneLoader.handle(), scene.width, scene.height);
         try {
-            HipNative.renderSetCamera(render, 0, HipCamera.pinholeSettings(scene)); // ClCamera.java:33-70
+            HipCamera.apply(render, scene, true);                                    // ClCamera.java:33-104
             int spp = HipNative.renderRun(render, scene.getSampleBuffer(), scene.spp, scene.getTargetSpp(), 1024,
                     () -> {
                         scene.postProcessFrame(se.llbit.util.TaskTracker.Task.NONE);  // :175-176

@@ -36,7 +36,7 @@ public class HipPreviewRenderer implements Renderer {
         sceneLoader.ensureLoad(scene);                                                   // :54
         long render = HipNative.renderCreate(ctx, sceneLoader.handle(), scene.width, scene.height);
         try {
-            HipNative.renderSetCamera(render, 0, HipCamera.pinholeSettings(scene));      // ClCamera.java:33-70
+            HipCamera.apply(render, scene, false);                                       // camera.generate(null, false), :72
             HipNative.renderPreview(render, imageData);                                  // kernel launch + blocking read, :104-110
             manager.redrawScreen();                                                      // :112
             postRender.getAsBoolean();                                                   // :113

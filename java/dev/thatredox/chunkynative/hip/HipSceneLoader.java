@@ -24,6 +24,7 @@ import se.llbit.chunky.renderer.scene.Scene;
 public class HipSceneLoader extends AbstractSceneLoader {
     private final long ctx;
     private long scene;
+    private boolean skyLoaded = false;
 
     public HipSceneLoader(long ctx) {
         this.ctx = ctx;
@@ -33,10 +34,31 @@ public class HipSceneLoader extends AbstractSceneLoader {
     public long handle() { return scene; }
 
     @Override
+    public boolean ensureLoad(Scene sceneObj) {
+        return this.ensureLoad(sceneObj, !skyLoaded);                       // ClSceneLoader.java:34-36
+    }
+
+    @Override
     public boolean load(int modCount, ResetReason resetReason, Scene sceneObj) {
-        // sky bake exactly as ClSky.java:43-58, then HipNative.sceneSetSky(scene, rgba, res, res, sunIntensity)
-        HipSky.upload(scene, sceneObj);
-        return super.load(modCount, resetReason, sceneObj);
+        if (this.modCount != modCount) {                                     // ClSceneLoader.java:40-48 (SkyState diffing
+            HipSky.upload(scene, sceneObj);                                  // is the maintainer's to keep: here the sky
+            skyLoaded = true;                                                // is re-baked whenever the scene changed)
+        }
+        Object before = this.blockPalette;
+        if (!super.load(modCount, resetReason, sceneObj)) return false;
+        if (this.blockPalette != before) {
+            // AbstractSceneLoader.load has packed new palettes, BVHs and sun (:93-141): hand them to the library —
+            // the OpenCL build does this lazily through ClPackedResourcePalette.get() when kernel arguments are set
+            ((HipPalette<PackedBlock>) this.blockPalette).upload();
+            ((HipPalette<PackedMaterial>) this.materialPalette.palette).upload();
+            ((HipPalette<PackedAabbModel>) this.aabbPalette).upload();
+            ((HipPalette<PackedQuadModel>) this.quadPalette).upload();
+            ((HipPalette<PackedTriangleModel>) this.trigPalette).upload();
+            HipNative.sceneSetBvh(scene, HipNative.BVH_WORLD, this.worldBvh);
+            HipNative.sceneSetBvh(scene, HipNative.BVH_ACTOR, this.actorBvh);
+            HipNative.sceneSetSun(scene, this.packedSun.pack().toIntArray());
+        }
+        return true;
     }
 
     @Override
@@ -52,10 +74,6 @@ public class HipSceneLoader extends AbstractSceneLoader {
     @Override protected ResourcePalette<PackedAabbModel> createAabbModelPalette() { return new HipPalette<>(scene, HipNative.PALETTE_AABB); }
     @Override protected ResourcePalette<PackedQuadModel> createQuadModelPalette() { return new HipPalette<>(scene, HipNative.PALETTE_QUAD); }
     @Override protected ResourcePalette<PackedTriangleModel> createTriangleModelPalette() { return new HipPalette<>(scene, HipNative.PALETTE_TRIG); }
-
-    /** Called by AbstractSceneLoader once the BVH node arrays are packed (AbstractSceneLoader.java:118-127). */
-    protected void uploadBvh(int which, int[] packedNodes) { HipNative.sceneSetBvh(scene, which, packedNodes); }
-    protected void uploadSun(PackedSun sun) { HipNative.sceneSetSun(scene, sun.pack().toIntArray()); }
 
     public void close() {
         if (scene != 0) { HipNative.sceneDestroy(scene); scene = 0; }
