@@ -225,6 +225,21 @@ def test_render_loop_options_match_oracle(gpu_instance, port, name, draw, depth,
     loader.close()
 
 
+@pytest.mark.parametrize("seed,size,entities,sun", [(11, 16, 0, True), (12, 16, 60, True), (13, 32, 30, False),
+                                                       (14, 48, 0, True), (15, 16, 24, True), (16, 32, 0, False)])
+def test_seeded_small_worlds_match_oracle(gpu_instance, port, seed, size, entities, sun):
+    """Small worlds from other seeds than the golden ones (dense in slab and plant models, emitters, a few entities;
+    octree depths 5-7, so the one- and two-level forms of the wide tree): bit-identical to the C restatement."""
+    sc = scenes.tiny_scene(seed=seed, size=size, width=72, height=48, entities=entities, sun_flag=sun)
+    seeds = scenes.java_random_ints(5, seed=seed)
+    loader, r = make_renderer(gpu_instance, sc)
+    r.render_passes(seeds)
+    assert_radiance(r.read(), port.render_passes(sc, seeds), f"seed {seed} size {size}")
+    np.testing.assert_array_equal(r.preview(), port.preview(sc))
+    r.close()
+    loader.close()
+
+
 def test_edge_cases(gpu_instance, port):
     sc = gs.make("outdoor").with_view(33, 17)          # ragged: not a multiple of the block or tile size
     loader, r = make_renderer(gpu_instance, sc)
