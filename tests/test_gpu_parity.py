@@ -240,6 +240,23 @@ def test_seeded_small_worlds_match_oracle(gpu_instance, port, seed, size, entiti
     loader.close()
 
 
+def test_reference_benchmark_scene_matches_oracle(gpu_instance, port):
+    """The reference's own benchmark octree (depth 10: a 16^3 top node over two 8^3 levels), its saved camera,
+    a small view: bit-identical to the C restatement."""
+    from chunkyclplugin_amd import octree2
+    try:
+        sc = octree2.cached_benchmark_scene(160, 90)
+    except FileNotFoundError:
+        pytest.skip("benchmark scene not cached (needs /root/reference once)")
+    assert sc.octree_depth == 10
+    seeds = scenes.java_random_ints(4)
+    loader, r = make_renderer(gpu_instance, sc)
+    r.render_passes(seeds)
+    assert_radiance(r.read(), port.render_passes(sc, seeds), "benchmark/OpenCL_test")
+    r.close()
+    loader.close()
+
+
 def test_edge_cases(gpu_instance, port):
     sc = gs.make("outdoor").with_view(33, 17)          # ragged: not a multiple of the block or tile size
     loader, r = make_renderer(gpu_instance, sc)
