@@ -948,18 +948,12 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
     unsigned long long t_begin = 0;
     if (STATS) t_begin = __builtin_amdgcn_s_memtime();
     PixelPool pool{0, 0};
-    int st;
-    {
-        WaveArgPtr A = fresh_args();
-        const SceneView S = arg_copy(&A->S);
-        const CameraView C = arg_copy(&A->C);
-        const ShardView T = arg_copy(&A->T);
-        if (G == 1)
-            st = next_sample_single<TREE>(S, C, T, A, pool, L, ST_NEXT, true);
-        else
-            st = next_sample<TREE, G>(S, C, T, A, pool, L, ctl, glds, ST_IDLE);
-        if (st == ST_SETUP) st = trace_setup<END>(S, L);
-    }
+    // Every lane starts free (G > 1) or finished (G = 1): the first samples are handed out by the loop itself, so the
+    // hand-over and the trace set-up exist ONCE in the kernel.  A second copy of them on another path of the loop (the
+    // "nobody is tracing" rounds used to have one) makes the compiler keep every path-state register twice and copy
+    // between the two sets on each iteration: ~80 v_mov per iteration, 7 % of all instructions issued.
+    int st = G == 1 ? ST_NEXT : ST_IDLE;
+    bool first_round = true;
     int idle_rounds = 0;
     for (;;) {
         if (BVH && __ballot(st == ST_TRACED)) {  // octree part of some traces just ended: entity BVHs next
@@ -971,23 +965,15 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
         const int n_shade = count_lanes(st == ST_SHADE);
         const int n_bvh = BVH ? count_lanes(st == ST_BVH) : 0;
         const int n_leaf = BVH ? count_lanes(st == ST_LEAF) : 0;
-        if ((n_march | n_block | n_shade | n_bvh | n_leaf) == 0) {
-            // nobody is tracing: everything is parked, so folding / pixel hand-out can always advance
-            if (G == 1 || __ballot(st != ST_DONE) == 0 || ++idle_rounds > 64) break;
-            WaveArgPtr A = fresh_args();
-            const SceneView S = arg_copy(&A->S);
-            const CameraView C = arg_copy(&A->C);
-            const ShardView T = arg_copy(&A->T);
-            st = next_sample<TREE, G>(S, C, T, A, pool, L, ctl, glds, st);
-            if (st == ST_SETUP) st = trace_setup<END>(S, L);
-            continue;
-        }
-        idle_rounds = 0;
+        // nobody is tracing: everything is parked, so folding / pixel hand-out can always advance (SHADE branch below)
+        const bool idle = (n_march | n_block | n_shade | n_bvh | n_leaf) == 0;
+        if (idle && !first_round && (G == 1 || __ballot(st != ST_DONE) == 0 || ++idle_rounds > 64)) break;
+        if (!idle) idle_rounds = 0;
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         int ph, n_ph1 = n_block;  // lanes served by a phase profiled as BLOCK (the BVH phases are)
         const int n_octree = n_march > n_block ? (n_march > n_shade ? n_march : n_shade) : (n_block > n_shade ? n_block : n_shade);
-        if (BVH && n_bvh > 0 && n_bvh >= n_octree && n_bvh >= n_leaf) {
+        if (!idle && BVH && n_bvh > 0 && n_bvh >= n_octree && n_bvh >= n_leaf) {
             ph = 1;  // profiled with BLOCK
             n_ph1 = n_bvh;
             const SceneView S = arg_copy(&fresh_args()->S);
@@ -1003,12 +989,12 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
                     ns = count_lanes(st == ST_SHADE);
                 } while (nv > 0 && nv >= nl && nv >= n_march && nv >= n_block && nv >= ns);
             }
-        } else if (BVH && n_leaf > 0 && n_leaf >= n_octree) {
+        } else if (!idle && BVH && n_leaf > 0 && n_leaf >= n_octree) {
             ph = 1;
             n_ph1 = n_leaf;
             const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_LEAF) st = leaf_phase(S, L, stack);
-        } else if (n_march * kWMarch >= n_block * kWBlock && n_march * kWMarch >= n_shade * kWShade) {
+        } else if (!idle && n_march * kWMarch >= n_block * kWBlock && n_march * kWMarch >= n_shade * kWShade) {
             ph = 0;
             // the few scalars MARCH needs are re-read here too (scalar cache hits): kept live across
             // the whole loop they are the first thing the allocator spills to VGPR lanes
@@ -1047,7 +1033,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
                     prof[1] -= (unsigned long long)n_march;
                 }
             }
-        } else if (n_block * kWBlock >= n_shade * kWShade) {
+        } else if (!idle && n_block * kWBlock >= n_shade * kWShade) {
             ph = 1;
             const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_BLOCK) st = block_phase<TREE, END>(S, L);
@@ -1058,13 +1044,13 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
             const RenderOpts O = arg_copy(&A->O);
             if (st == ST_SHADE) st = shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
             // G > 1: hand-over rounds cost ~300 instructions; wait until a few finished paths share one
-            if (count_lanes(st == ST_NEXT) >= (G == 1 ? 1 : kHandoverBatch)) {
+            if (idle || count_lanes(st == ST_NEXT) >= (G == 1 ? 1 : kHandoverBatch)) {
                 unsigned long long th = 0;
                 if (STATS) th = __builtin_amdgcn_s_memtime();
                 const CameraView C = arg_copy(&A->C);
                 const ShardView T = arg_copy(&A->T);
                 if (G == 1)
-                    st = next_sample_single<TREE>(S, C, T, A, pool, L, st, false);
+                    st = next_sample_single<TREE>(S, C, T, A, pool, L, st, first_round);
                 else
                     st = next_sample<TREE, G, STATS>(S, C, T, A, pool, L, ctl, glds, st, &parts);
                 if (STATS) {
@@ -1075,6 +1061,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
             part_begin<STATS>(&parts);
             if (st == ST_SETUP) st = trace_setup<END>(S, L);
             part_end<STATS>(&parts, PT_SETUP);
+            first_round = false;
         }
         if (STATS) {
             unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
