@@ -615,11 +615,13 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
         // the shadow trace (the block and triangle tests leave the main record alone for shadow rays)
         const float e = main_trace ? 1.0f : L.h.emittance;
         L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, e);
-        if (main_trace) return ST_NEXT;
     }
     part_end<PROF>(pt, PT_SKY);
+    // one exit: a main ray that reached the sky is finished; every other lane goes on below
+    bool finished = !hit && main_trace;
     bool bounce = true, to_sun = false;
-    if (main_trace) {
+    if (finished) {
+    } else if (main_trace) {
         // the hit point (K/kernel.h:21-23) becomes the origin of the shadow ray and stays there until the bounce
         L.o = L.o + L.d * (L.h.distance - kOffset);
         // applyRayColor (K/kernel.h:33-44)
@@ -637,7 +639,7 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
     // for the lanes that bounce.  A lane does one or the other, and both have the same skeleton — two draws,
     // sin/cos of 2*pi*x2, a square root, a vector, its reciprocal length — so the expensive steps are issued
     // once for both kinds of lane and only the cheap vector algebra in between is specific.
-    {
+    if (!finished) {
         const float x1 = rt_pcg_float(&L.rng), x2 = rt_pcg_float(&L.rng);
         float sn, cs;
         rt_sincos(2 * RT_PI_F * x2, &sn, &cs);
@@ -675,11 +677,11 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
             L.o = L.o + L.d * kOffset;
             L.depth += 1;
             L.h.distance = rt_inf();
-            if (!(L.depth < O.max_depth)) return ST_NEXT;
+            finished = !(L.depth < O.max_depth);
         }
     }
     part_end<PROF>(pt, PT_SAMPLING);
-    return ST_SETUP;
+    return finished ? ST_NEXT : ST_SETUP;
 }
 
 // SHADE, part 2 for G = 1 (one lane per pixel), called from wave-uniform control flow (the pixel
