@@ -619,7 +619,7 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
     part_end<PROF>(pt, PT_SKY);
     // one exit: a main ray that reached the sky is finished; every other lane goes on below
     bool finished = !hit && main_trace;
-    bool bounce = true, to_sun = false;
+    bool to_sun = false;  // start a shadow ray towards the sun; otherwise bounce
     if (finished) {
     } else if (main_trace) {
         // the hit point (K/kernel.h:21-23) becomes the origin of the shadow ray and stays there until the bounce
@@ -628,10 +628,7 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
         f3 c = mk3(L.h.color.x, L.h.color.y, L.h.color.z);
         L.throughput = L.throughput * c;
         L.radiance = L.radiance + (c * (L.h.emittance * O.emitter_scale)) * L.throughput;
-        if (S.sun_flags & 1) {
-            to_sun = true;
-            bounce = false;
-        }
+        if (S.sun_flags & 1) to_sun = true;
     } else {
         L.shadow = false;
     }
@@ -934,7 +931,7 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
     L.bvh_base = nullptr;
     L.bvh_dist = 0;
     // per-group radiance buffers behind the BVH stacks in dynamic LDS
-    GroupLds glds{nullptr};
+    GroupLds glds{nullptr, nullptr};
     if (G > 1) {
         constexpr int kRing = ring_size(G);
         const unsigned stack_bytes = fresh_args()->stack_bytes;
