@@ -16,9 +16,14 @@ per-rank framebuffers to rank 0 inside the timed region (the read-back).  Total 
 N grows => "scaling": "strong".
 
 The JSON line also carries:
-  roofline     — HBM-bound; achieved = algorithmic bytes per sample of the reference's access stream
-                 (counted by the CPU oracle on a row-sample of this same view) x
-                 samples per launch / mean launch duration from HIP events on the launch stream.
+  roofline     — the contract figure: achieved = ALGORITHMIC bytes per sample of the reference's
+                 access stream (counted by the CPU oracle on a row-sample of this same view) x samples per launch /
+                 mean launch duration from HIP events on the launch stream, against the 8 TB/s HBM peak.  It is a
+                 work-rate convention: the scene is cache-resident, so physical HBM traffic is ~1 % of it.  `traffic`
+                 (PMC FETCH_SIZE x2 + WRITE_SIZE per launch) and `valu` (VALU issue share and lane utilisation — the
+                 real limiter) come from the committed PMC summary named in `pmc_source` and are attached only when
+                 that summary was collected for the kernel / launch shape of this run; otherwise they are null.
+  per_rank     — N > 1: every rank's kernel milliseconds (HIP events) and the milliseconds of the read-back reduce.
   cpu_baseline — the C restatement of the reference kernel (oracle/port.c, kind "port") timed on
                  this box's host cores on a bounded row-sample of the same workload (rank 0, N=1).
 """
@@ -71,6 +76,9 @@ def main():
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the oracle row-sample too: nothing under oracle/ is loaded, built or spawned (profiler runs)")
+    ap.add_argument("--dump", default="", help="rank 0 writes the final (reduced) framebuffer to this .npy file")
     ap.add_argument("--emulate-world", type=int, default=0, help="rig: render only rank 0's share of an N-GPU split on one GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rigs")
     ap.add_argument("--one-device", action="store_true", help="rig: every rank uses GPU 0 (1-GPU box, with --backend gloo)")
@@ -108,6 +116,7 @@ def main():
     r.set_option(native.OPT_KERNEL, args.kernel)
     r.set_shard(rank, args.emulate_world or world, args.tile)
     fb = torch.zeros(3 * n_pix, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the passes on the library's: order them (chunky_hip.h)
     r.set_device_buffer(fb.data_ptr())
 
     total_passes = (args.warmup + args.steps) * args.passes
@@ -131,7 +140,10 @@ def main():
         r.render_passes(seeds[spp:spp + args.passes], first_buffer_spp=spp, sync=False)
         spp += args.passes
     r.sync()
+    t_reduce = time.perf_counter()
     parallel.reduce_framebuffer(fb, dst=0)  # the read-back collective (one RCCL reduce; no-op at N=1)
+    torch.cuda.synchronize()
+    reduce_ms = (time.perf_counter() - t_reduce) * 1e3
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -139,26 +151,48 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kernel_ms, launches = r.kernel_time()
+    info = r.kernel_info()
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([kernel_ms, reduce_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = {"kernel_ms": [round(float(g[0]), 3) for g in gathered], "reduce_ms": [round(float(g[1]), 3) for g in gathered],
+                    "note": "kernel_ms = sum of this rank's launches in the timed region (HIP events); reduce_ms = host time of "
+                            "the one read-back reduce incl. waiting for the slowest rank"}
+    if rank == 0 and args.dump:
+        np.save(args.dump, fb.cpu().numpy())
 
     if rank == 0:
-        samples = n_pix * args.steps * args.passes
+        local_slots = parallel.local_slots(n_pix, 0, args.emulate_world or world, args.tile)
+        # an emulated share renders only rank 0's tiles: count what was rendered, and say so
+        samples = (min(local_slots, n_pix) if args.emulate_world else n_pix) * args.steps * args.passes
         value = samples / dt / 1e6
         # ---- roofline: algorithmic bytes of the reference access stream on this view ---------------
         threads = os.cpu_count() or 1
-        rows = sample_rows(sc.height, 36)
-        n_s, _, ctr = oracle_row_sample(sc, seeds[:1], rows, threads, count=True)
-        from oracle import binding
-        bytes_per_sample = binding.algorithmic_bytes(ctr)
-        local_slots = parallel.local_slots(n_pix, 0, world, args.tile)
         passes_per_launch = min(args.passes, 256)
         launch_ms = kernel_ms / max(launches, 1)
         samples_per_launch = min(local_slots, n_pix) * passes_per_launch
-        achieved = bytes_per_sample * samples_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = None
+        bytes_per_sample, n_s, rows = None, 0, []
+        if not args.no_roofline:
+            from oracle import binding
+            binding.port(build=not args.no_cpu)  # --no-cpu runs (profiler passes) never spawn a compiler
+            rows = sample_rows(sc.height, 36)
+            n_s, _, ctr = oracle_row_sample(sc, seeds[:1], rows, threads, count=True)
+            bytes_per_sample = binding.algorithmic_bytes(ctr)
+        achieved = bytes_per_sample * samples_per_launch / (launch_ms * 1e-3) / 1e9 if (launch_ms > 0 and bytes_per_sample) else 0.0
+        kernel_name = "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh")
+        traffic, valu, pmc_source = None, None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                pm = json.load(open(tp))
+                # only for the launch shape the counters were collected on
+                if (pm.get("kernel_info") == [info["tree"], info["group"], int(info["bvh"])] and pm.get("passes_per_launch") == passes_per_launch
+                        and pm.get("samples_per_launch") == samples_per_launch and args.kernel == 0):
+                    traffic = pm.get("hbm_bytes_per_launch")
+                    valu = pm.get("valu")
+                    pmc_source = pm.get("source")
             except Exception:
                 traffic = None
         out = {
@@ -174,12 +208,21 @@ def main():
                                       f"one RCCL reduce per read-back", "kernel_variant": args.kernel},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
-                         "kernel": "render", "launches": launches, "launch_ms": round(launch_ms, 4),
+                         "achieved_is": "algorithmic bytes of the reference access stream / launch time (SURVEY 8d), "
+                                        "not physical HBM traffic: the scene is cache-resident",
+                         "physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and launch_ms > 0 else None,
+                         "valu": valu, "pmc_source": pmc_source,
+                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 1) if bytes_per_sample else None,
+                         "kernel": kernel_name, "launches": launches, "launch_ms": round(launch_ms, 4),
                          "samples_per_launch": samples_per_launch,
                          "counted_on": f"{n_s} samples ({len(rows)} rows of this view, seed 0)"},
         }
-        if world == 1 and not args.no_cpu:
+        if args.emulate_world:
+            out["emulated_world"] = args.emulate_world
+            out["metric"] += f" — EMULATED rank-0 share of a {args.emulate_world}-GPU split on one GPU (not a multi-GPU result)"
+        if per_rank:
+            out["per_rank"] = per_rank
+        if world == 1 and not args.no_cpu and not args.no_roofline:
             # bounded CPU leg: the SAME full-resolution view, whole image, P passes with P sized from a
             # calibration run so the leg costs about --cpu-seconds of wall time on all host cores
             all_rows = sample_rows(sc.height, sc.height)

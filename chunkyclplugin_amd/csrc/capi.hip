@@ -107,6 +107,7 @@ struct chunky_render {
     std::vector<hipEvent_t> free_events;
     float timed_ms = 0;
     int timed_launches = 0;
+    KernelChoice last_choice{0, 0, 0, 0};  // what the most recent launch ran (chunky_render_kernel_info)
     ~chunky_render() {
         for (auto& p : pending) {
             (void)hipEventDestroy(p.first);
@@ -650,7 +651,8 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
         HIP_TRY(get_event(r, &e0));
         HIP_TRY(get_event(r, &e1));
         HIP_TRY(hipEventRecord(e0, r->ctx->stream));
-        HIP_TRY(launch_render(r->kernel_variant, S, r->cam, r->opts, r->shard, ps, r->fb, (int*)r->work_counter.p, r->ctx->stream));
+        HIP_TRY(launch_render(r->kernel_variant, S, r->cam, r->opts, r->shard, ps, r->fb, (int*)r->work_counter.p, r->ctx->stream,
+                              &r->last_choice));
         HIP_TRY(hipEventRecord(e1, r->ctx->stream));
         r->pending.emplace_back(e0, e1);
         done += ps.n;
@@ -680,6 +682,16 @@ extern "C" int chunky_render_kernel_time(chunky_render* r, float* total_ms, int*
     if (launches) *launches = r->timed_launches;
     r->timed_ms = 0;
     r->timed_launches = 0;
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out4[4]) {
+    LOCK_RENDER(r);
+    if (!out4) return fail(CHUNKY_E_INVALID, "kernel_info: NULL output");
+    out4[0] = r->last_choice.tree;
+    out4[1] = r->last_choice.group;
+    out4[2] = r->last_choice.bvh;
+    out4[3] = r->last_choice.blocks;
     return CHUNKY_OK;
 }
 

@@ -1291,7 +1291,7 @@ static size_t stack_lds_bytes(const SceneView& S, int block) {
 }
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
-                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream) {
+                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen) {
     if (!(variant & 2) && work_counter) {
         const bool stats = (variant & 4) != 0;  // work_counter[2..] = 9 x u64 phase profile
         // wave-scheduled persistent kernel: one resident grid, lanes pull pixels from a counter
@@ -1330,16 +1330,22 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         if (group != 1 && group != 8 && group != 16 && group != 32) group = 8;
         const bool has_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
         if (group == 32 && (has_bvh || stats)) group = 16;
-        if (group > 1) lds += (size_t)(block / group) * (2 * ring_size(group) * 16 + 64);
+        // the instantiations that exist: every tree form for the plain kernels at G = 1 and 8; the dense-top forms of
+        // the two benchmark depths (9 and 10) for the rest; `tree` becomes the form actually used
         Kernel k;
         if (has_bvh && !stats && group > 1) {
+            if (tree != 17 && tree != 18) tree = -1;
             if (group == 16)
                 k = tree == 17 ? render_waves<17, false, 16, true> : (tree == 18 ? render_waves<18, false, 16, true> : render_waves<-1, false, 16, true>);
             else
                 k = tree == 17 ? render_waves<17, false, 8, true> : (tree == 18 ? render_waves<18, false, 8, true> : render_waves<-1, false, 8, true>);
         } else if (has_bvh) {
+            tree = -1;
+            group = 1;
             k = stats ? render_waves<-1, true, 1, true> : render_waves<-1, false, 1, true>;
         } else if (stats) {
+            if (tree != 17) tree = -1;
+            if (group != 1) group = 8;
             k = tree == 17 ? (group == 1 ? render_waves<17, true, 1> : render_waves<17, true, 8>)
                            : (group == 1 ? render_waves<-1, true, 1> : render_waves<-1, true, 8>);
         } else if (group == 1) {
@@ -1349,11 +1355,13 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
                 case 17: k = render_waves<17, false, 1>; break;
                 case 18: k = render_waves<18, false, 1>; break;
                 case 19: k = render_waves<19, false, 1>; break;
-                default: k = render_waves<-1, false, 1>; break;
+                default: tree = -1; k = render_waves<-1, false, 1>; break;
             }
         } else if (group == 32) {
+            if (tree != 17 && tree != 18) tree = -1;
             k = tree == 17 ? render_waves<17, false, 32> : (tree == 18 ? render_waves<18, false, 32> : render_waves<-1, false, 32>);
         } else if (group == 16) {
+            if (tree != 17 && tree != 18) tree = -1;
             k = tree == 17 ? render_waves<17, false, 16> : (tree == 18 ? render_waves<18, false, 16> : render_waves<-1, false, 16>);
         } else {
             switch (tree) {
@@ -1362,9 +1370,10 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
                 case 17: k = render_waves<17, false, 8>; break;
                 case 18: k = render_waves<18, false, 8>; break;
                 case 19: k = render_waves<19, false, 8>; break;
-                default: k = render_waves<-1, false, 8>; break;
+                default: tree = -1; k = render_waves<-1, false, 8>; break;
             }
         }
+        if (group > 1) lds += (size_t)(block / group) * (2 * ring_size(group) * 16 + 64);
         int occ = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
         if (e != hipSuccess) return e;
@@ -1374,6 +1383,7 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         int grid = n_cu * bpc;
         if ((long long)grid > want) grid = (int)want;
         if (grid <= 0 || P.n <= 0) return hipSuccess;
+        if (chosen) *chosen = KernelChoice{tree, group, has_bvh ? 1 : 0, grid};
         e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
         WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)stack};
@@ -1383,6 +1393,7 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
     const int block = 256;
     int grid = (T.n_local + block - 1) / block;
     if (grid <= 0 || P.n <= 0) return hipSuccess;
+    if (chosen) *chosen = KernelChoice{use_wide(variant, S) ? -1 : 0, 0, (!S.world_bvh_empty || !S.actor_bvh_empty) ? 1 : 0, grid};
     if (use_wide(variant, S))
         hipLaunchKernelGGL(render_lanes<-1>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
     else

@@ -38,8 +38,18 @@ struct PassSeeds {
     int seed[kMaxPassesPerLaunch];
 };
 
+// What launch_render picked for a launch (chunky_render_kernel_info): the tests assert that the instantiation they
+// mean to compare with the oracle is the one that ran.
+struct KernelChoice {
+    int tree;    // leaf-lookup form: 0 reference layout, -1 generic wide tree, 16 + n dense top over n 3-bit levels
+    int group;   // lanes per pixel (render_waves); 0 = render_lanes (one lane per pixel for the whole launch)
+    int bvh;     // entity-BVH phases compiled in
+    int blocks;  // workgroups launched
+};
+
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
-                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream);
+                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream,
+                         KernelChoice* chosen = nullptr);
 hipError_t launch_trace_records(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
                                 const int* gids_dev, int n, HitRecord* out, int* counts, float* radiance,
                                 hipStream_t stream);

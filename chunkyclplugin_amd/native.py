@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
             "chunky_render_kernel_time": [vp, C.POINTER(f32), C.POINTER(C.c_int)],
             "chunky_render_preview": [vp, vp],
             "chunky_render_phase_stats": [vp, vp, C.c_int],
+            "chunky_render_kernel_info": [vp, vp],
             "chunky_render_trace_records": [vp, i32, vp, C.c_int, vp, vp, vp],
             "chunky_render_run": [vp, vp, C.POINTER(i32), i32, i32, POST_RENDER_FN, vp],
             "chunky_java_random_ints": [i64, vp, C.c_int],

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import gzip
 import json
+import os
 import math
 import struct
 import zlib
@@ -248,16 +249,30 @@ def load_scene(octree2_path: str, json_path: str = None, width: int = 1920, heig
                               height=height, name="octree2:" + octree2_path.split("/")[-1])
 
 
+FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "benchmark_OpenCL_test.npz")
+REFERENCE_SCENE = "/root/reference/benchmark/OpenCL_test/OpenCL_test"
+
+
 def cached_benchmark_scene(width: int = 1920, height: int = 1080) -> scenes.PackedScene:
-    """The reference's `benchmark/OpenCL_test` scene (BASELINE.json configs[0]/[1]).  Read from
-    /root/reference where that exists and kept, as packed arrays, under .scene_cache/ so that the GPU
-    box (which has no /root/reference) gets the same input; raises FileNotFoundError when neither exists."""
-    import os
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".scene_cache")
-    path = os.path.join(root, "octree2_OpenCL_test.npz")
-    src = "/root/reference/benchmark/OpenCL_test/OpenCL_test"
-    if not os.path.exists(path):
-        if not os.path.exists(src + ".octree2"):
-            raise FileNotFoundError("benchmark scene: neither " + src + ".octree2 nor " + path)
-        scenes.save_scene(load_scene(src + ".octree2", src + ".json"), path)
-    return scenes.load_scene(path).with_view(width, height)
+    """The reference's `benchmark/OpenCL_test` scene (BASELINE.json configs[0]/[1]) as packed arrays.
+
+    The committed fixture tests/golden/benchmark_OpenCL_test.npz is this module's conversion of the reference's data
+    files (`OpenCL_test.octree2` + `.json`), written by `python -m chunkyclplugin_amd.octree2 --write-fixture` where
+    /root/reference exists; the GPU box has no /root/reference and reads the fixture.  Raises FileNotFoundError when
+    neither exists — callers must not skip silently."""
+    if not os.path.exists(FIXTURE):
+        if not os.path.exists(REFERENCE_SCENE + ".octree2"):
+            raise FileNotFoundError("benchmark scene: neither " + REFERENCE_SCENE + ".octree2 nor " + FIXTURE)
+        write_fixture()
+    return scenes.load_scene(FIXTURE).with_view(width, height)
+
+
+def write_fixture() -> str:
+    scenes.save_scene(load_scene(REFERENCE_SCENE + ".octree2", REFERENCE_SCENE + ".json"), FIXTURE, compressed=True)
+    return FIXTURE
+
+
+if __name__ == "__main__":
+    import sys
+    if "--write-fixture" in sys.argv:
+        print(write_fixture())

@@ -182,6 +182,12 @@ class HipPathTracingRenderer:
         check(native.lib().chunky_render_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_info(self) -> dict:
+        """The kernel instantiation the last launch ran: tree form, lanes per pixel, entity-BVH phases, workgroups."""
+        out = np.zeros(4, np.int32)
+        check(native.lib().chunky_render_kernel_info(self._h, ptr(out)))
+        return {"tree": int(out[0]), "group": int(out[1]), "bvh": bool(out[2]), "blocks": int(out[3])}
+
     def phase_stats(self, reset: bool = True) -> dict:
         out = np.zeros(24, np.uint64)
         check(native.lib().chunky_render_phase_stats(self._h, ptr(out), 1 if reset else 0))

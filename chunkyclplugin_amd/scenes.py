@@ -690,11 +690,11 @@ _ARRAY_FIELDS = ("octree", "block_palette", "material_palette", "aabb_models", "
                  "actor_bvh", "bvh_trigs", "atlas", "sky", "sun", "camera")
 
 
-def save_scene(sc: PackedScene, path: str) -> None:
+def save_scene(sc: PackedScene, path: str, compressed: bool = False) -> None:
     import os
     os.makedirs(os.path.dirname(path), exist_ok=True)
     tmp = path + f".{os.getpid()}.tmp.npz"
-    np.savez(tmp, meta=np.array([sc.octree_depth, sc.projector_type, sc.width, sc.height], np.int64),
+    (np.savez_compressed if compressed else np.savez)(tmp, meta=np.array([sc.octree_depth, sc.projector_type, sc.width, sc.height], np.int64),
              sky_intensity=np.float64(sc.sky_intensity), name=np.array(sc.name),
              **{f: getattr(sc, f) for f in _ARRAY_FIELDS})
     os.replace(tmp, path)

@@ -125,6 +125,13 @@ int chunky_render_read(chunky_render* r, float* out, int64_t n_floats);
  * kernels run on: total milliseconds and number of launches. */
 int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches);
 
+/* Which kernel instantiation the most recent chunky_render_passes launch ran (no reference counterpart; the parity
+ * tests assert it, so that a comparison with the oracle is a comparison of the kernel that is timed): out4 =
+ * {tree form: 0 reference octree layout (K/octree.h:81-89), -1 generic wide tree, 16 + n dense top node over n levels
+ * of 8x8x8 nodes; lanes per pixel (0 = one lane per pixel for the whole launch); entity-BVH phases present (K/bvh.h:22-113);
+ * workgroups launched}. */
+int chunky_render_kernel_info(chunky_render* r, int32_t out4[4]);
+
 /* Profile of the wave-scheduled kernel, filled only while CHUNKY_OPT_KERNEL has bit 2 set: for each of
  * the phases MARCH, BLOCK, SHADE the number of wave-level executions, the lanes active in them and
  * the shader cycles spent (s_memtime), summed over all waves since the last reset (9 values), then

@@ -1,0 +1,73 @@
+"""The N > 1 path with the HIP kernels under a real process group: bench.py itself, launched by torch.distributed.run
+as 2 (and 4) ranks that share GPU 0 (`--one-device --backend gloo`: RCCL refuses two ranks on one device, so the
+framebuffer reduce is staged through the host by parallel.reduce_framebuffer; everything else — one process per rank,
+chunky_render_set_shard, the per-rank framebuffer tensor, the read-back collective, the timing protocol — is the code
+the 2/4/8-GPU runs use).  Rank 0's reduced framebuffer must equal the single-process image bit for bit, and whole
+rows of it must equal the oracle.
+
+The ranks are started as child processes of a launcher that never touches the GPU (torch.distributed.run); nothing
+here replaces a process that has initialised HIP."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from chunkyclplugin_amd import native, scenes
+from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, CHUNKS, PASSES = 640, 360, 8, 48
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bench(world, dump, extra=()):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
+           "--passes", str(PASSES), "--width", str(W), "--height", str(H), "--chunks", str(CHUNKS), "--one-device", "--backend", "gloo",
+           "--no-cpu", "--dump", dump, *extra]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def single_rank_image(gpu_instance):
+    sc = scenes.cached_outdoor_world(chunks=CHUNKS, height=256, width=W, img_height=H)
+    loader = HipSceneLoader(gpu_instance)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, W, H)
+    r.set_camera(sc.projector_type, sc.camera)
+    r.render_passes(native.java_random_ints(PASSES))
+    img = r.read()
+    r.close()
+    loader.close()
+    return sc, img
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_device_reduce_to_the_single_rank_image(tmp_path, port, single_rank_image, world):
+    sc, want = single_rank_image
+    dump = str(tmp_path / f"fb{world}.npy")
+    line = _run_bench(world, dump)
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["unit"] == "Msamples/s"
+    assert len(line["per_rank"]["kernel_ms"]) == world and min(line["per_rank"]["kernel_ms"]) > 0
+    got = np.load(dump)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    # and the reduced image is the oracle's on whole rows (so "equal to the single-rank image" is not two wrongs)
+    rows = (5, H // 3, H // 2, H - 2)
+    gids = np.concatenate([np.arange(y * W, (y + 1) * W) for y in rows]).astype(np.int32)
+    ref = port.render_gids(sc, native.java_random_ints(PASSES), gids, threads=os.cpu_count() or 8).reshape(-1, 3)[gids]
+    np.testing.assert_array_equal(got.reshape(-1, 3)[gids].view(np.uint32), ref.view(np.uint32))

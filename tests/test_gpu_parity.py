@@ -244,10 +244,7 @@ def test_reference_benchmark_scene_matches_oracle(gpu_instance, port):
     """The reference's own benchmark octree (depth 10: a 16^3 top node over two 8^3 levels), its saved camera,
     a small view: bit-identical to the C restatement."""
     from chunkyclplugin_amd import octree2
-    try:
-        sc = octree2.cached_benchmark_scene(160, 90)
-    except FileNotFoundError:
-        pytest.skip("benchmark scene not cached (needs /root/reference once)")
+    sc = octree2.cached_benchmark_scene(160, 90)  # committed fixture tests/golden/benchmark_OpenCL_test.npz: never skipped
     assert sc.octree_depth == 10
     seeds = scenes.java_random_ints(4)
     loader, r = make_renderer(gpu_instance, sc)

@@ -1,0 +1,182 @@
+"""The kernel instantiations that bench.py / tools/config_bench.py TIME, compared with the oracle.
+
+`launch_render` picks the lookup form (TREE), the lanes per pixel (G) and the entity-BVH phases from the scene, the shard
+size and the pass count, so a small test scene never runs the kernel the benchmark runs.  These tests render the
+benchmark workloads themselves — full 1920x1080 views, 32 or more passes per launch — assert through
+chunky_render_kernel_info that the instantiation is the timed one, and compare whole image rows with the C restatement
+(oracle/port.c `port_render_gids`), bit for bit.  Reference loops covered: K/rayTracer.cl:93-112, K/octree.h:66-106,
+K/bvh.h:22-113."""
+import os
+
+import numpy as np
+import pytest
+
+from chunkyclplugin_amd import native, parallel, scenes
+from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
+
+pytestmark = pytest.mark.gpu
+THREADS = os.cpu_count() or 8
+ROWS = (7, 101, 263, 411, 540, 688, 799, 931, 1003, 1079)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def make(gpu_instance, sc):
+    loader = HipSceneLoader(gpu_instance)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, sc.width, sc.height)
+    r.set_camera(sc.projector_type, sc.camera)
+    return loader, r
+
+
+def row_gids(sc, rows=ROWS):
+    rows = [min(y, sc.height - 1) for y in rows]
+    return np.concatenate([np.arange(y * sc.width, (y + 1) * sc.width) for y in rows]).astype(np.int32)
+
+
+def compare_rows(r, port, sc, seeds, gids, what, first=0):
+    got = r.read().reshape(-1, 3)[gids]
+    want = port.render_gids(sc, seeds, gids, first_spp=first, threads=THREADS).reshape(-1, 3)[gids]
+    same = (bits(got) == bits(want)).all(axis=1)
+    if not same.all():
+        rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-6)
+        pytest.fail(f"{what}: {int((~same).sum())} of {len(gids)} pixels differ from the oracle "
+                    f"(max rel err {np.nanmax(rel):.3e}, first gid {int(gids[np.argmin(same)])})")
+    assert np.isfinite(got).all() and got.max() > 0, what
+
+
+@pytest.fixture(scope="module")
+def outdoor():
+    return scenes.cached_outdoor_world(chunks=32, height=256)  # BASELINE configs[2], 1920x1080: what bench.py renders
+
+
+def test_headline_kernel_128_passes(gpu_instance, port, outdoor):
+    """bench.py's step: one 128-pass launch of render_waves<17, false, 8> over the whole 1080p image."""
+    sc = outdoor
+    seeds = native.java_random_ints(128)
+    loader, r = make(gpu_instance, sc)
+    r.render_passes(seeds)
+    assert r.kernel_info() == {"tree": 17, "group": 8, "bvh": False, "blocks": r.kernel_info()["blocks"]}
+    assert r.kernel_info()["blocks"] >= 256 * 4
+    compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[::2]), "outdoor 128 passes")
+    # the second step of the bench continues the running mean at bufferSpp = 128 (K/rayTracer.cl:109-112)
+    more = native.java_random_ints(160)[128:]
+    r.render_passes(more, first_buffer_spp=128)
+    g = row_gids(sc, (263, 931))
+    got = r.read().reshape(-1, 3)[g]
+    want = port.render_gids(sc, seeds, g, threads=THREADS)
+    want = port.render_gids(sc, more, g, first_spp=128, res=want, threads=THREADS).reshape(-1, 3)[g]
+    np.testing.assert_array_equal(bits(got), bits(want))
+    r.close()
+    loader.close()
+
+
+@pytest.mark.parametrize("world,passes,group", [(1, 32, 8), (4, 32, 16), (8, 64, 32), (2, 48, 8)])
+def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group):
+    """The tile split of bench.py --gpus N (rank 1 of N, 256-pixel tiles): a quarter of the image runs 16 lanes per
+    pixel, an eighth 32 — the instantiations the 4- and 8-GPU lines time."""
+    sc = outdoor
+    seeds = native.java_random_ints(passes)
+    loader, r = make(gpu_instance, sc)
+    rank = 1 if world > 1 else 0
+    r.set_shard(rank, world, 256)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["group"], info["bvh"]) == (17, group, False), info
+    own = parallel.owned_gids(sc.width * sc.height, rank, world, 256)
+    rows = row_gids(sc)
+    mine = np.intersect1d(rows, own)
+    assert mine.size >= rows.size // world - 256
+    compare_rows(r, port, sc, seeds, mine, f"outdoor share 1/{world}")
+    others = np.setdiff1d(rows, own)
+    assert not r.read().reshape(-1, 3)[others].any()          # pixels of other ranks stay zero (the reduce adds them)
+    r.close()
+    loader.close()
+
+
+def test_city_kernel(gpu_instance, port):
+    """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_waves<18, false, 8>."""
+    from chunkyclplugin_amd import octree2
+    sc = octree2.cached_benchmark_scene(1920, 1080)   # raises when the fixture is missing: never skipped silently
+    seeds = native.java_random_ints(64)
+    loader, r = make(gpu_instance, sc)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["group"], info["bvh"]) == (18, 8, False), info
+    compare_rows(r, port, sc, seeds, row_gids(sc), "city 64 passes")
+    r.set_shard(3, 8, 256)
+    r.reset()
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["group"]) == (18, 32), info
+    own = parallel.owned_gids(sc.width * sc.height, 3, 8, 256)
+    compare_rows(r, port, sc, seeds, np.intersect1d(row_gids(sc), own), "city share 1/8")
+    r.close()
+    loader.close()
+
+
+def test_indoor_kernel(gpu_instance, port):
+    """BASELINE configs[3]: the emitter-lit room of tools/config_bench.py (sun flag 0), 1920x1080, 32 passes."""
+    sc = scenes.indoor_room(size=64, width=1920, img_height=1080)
+    seeds = native.java_random_ints(32)
+    loader, r = make(gpu_instance, sc)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["group"], info["bvh"]) == (17, 8, False), info
+    compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[1::2]), "indoor 32 passes")
+    r.close()
+    loader.close()
+
+
+@pytest.fixture(scope="module")
+def entity_world(outdoor):
+    # BASELINE configs[4] as tools/config_bench.py builds it: 100 000 world + 5 000 actor triangles
+    return scenes.add_entities(outdoor, 100000, seed=11, actor_tris=5000, region=((40, 90, 40), (470, 170, 470)))
+
+
+@pytest.mark.parametrize("world,passes,group", [(1, 16, 8), (4, 32, 16)])
+def test_entity_kernels(gpu_instance, port, entity_world, world, passes, group):
+    """render_waves<17, false, 8 | 16, true> on the 100 k-triangle world: BVHs of height ~17, both BVHs walked."""
+    sc = entity_world
+    seeds = native.java_random_ints(passes)
+    loader, r = make(gpu_instance, sc)
+    rank = world - 1
+    r.set_shard(rank, world, 256)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["group"], info["bvh"]) == (17, group, True), info
+    own = parallel.owned_gids(sc.width * sc.height, rank, world, 256)
+    mine = np.intersect1d(row_gids(sc, (101, 411, 540, 799, 1003)), own)
+    compare_rows(r, port, sc, seeds, mine, f"entities share 1/{world}")
+    r.close()
+    loader.close()
+
+
+def test_entity_trace_records(gpu_instance, port, entity_world):
+    """Every closestIntersect of one sample on ~100 pixels of the 100 k-triangle world: hit flags and block indices exact,
+    every float field bit-identical (octree + world BVH + actor BVH, main and shadow traces)."""
+    sc = entity_world
+    loader, r = make(gpu_instance, sc)
+    gids = np.arange(1920 * 300 + 5, 1920 * 1080, 1920 * 780 // 100 + 13, dtype=np.int32)[:100]
+    seed = int(native.java_random_ints(3)[2])
+    rec, cnt, rad = r.trace_records(seed, gids)
+    port.counters(enable=True, reset=True)
+    port.counters(reset=True)
+    for i, gid in enumerate(gids):
+        want, wrad = port.trace_records(sc, seed, int(gid))
+        n = int(cnt[i])
+        assert n == len(want), (gid, n, len(want))
+        got = rec[i, :n]
+        assert got["hit"].tolist() == want["hit"].tolist(), gid
+        assert got["material"].tolist() == want["material"].tolist(), gid
+        for f in ("distance", "normal", "color", "emittance"):
+            np.testing.assert_array_equal(bits(got[f]), bits(want[f]), err_msg=f"gid {gid} {f}")
+        hit = want["hit"] == 1
+        np.testing.assert_array_equal(bits(got["point"][hit]), bits(want["point"][hit]))
+        np.testing.assert_array_equal(bits(rad[i]), bits(wrad))
+    c = port.counters(enable=False, reset=True)
+    assert c["tri"] > 100 and c["bvh_inner"] > 1000, f"the sample hardly exercises the BVH path: {c}"
+    r.close()
+    loader.close()
