@@ -181,14 +181,15 @@ def main():
             n_s, _, ctr = oracle_row_sample(sc, seeds[:1], rows, threads, count=True)
             bytes_per_sample = binding.algorithmic_bytes(ctr)
         achieved = bytes_per_sample * samples_per_launch / (launch_ms * 1e-3) / 1e9 if (launch_ms > 0 and bytes_per_sample) else 0.0
-        kernel_name = "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh")
+        kernel_name = ("render_pool<%d,%d>+fold_kernel" % (info["tree"], info["pool"]) if info["pool"] >= 0 else
+                       "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh"))
         traffic, valu, pmc_source = None, None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 pm = json.load(open(tp))
                 # only for the launch shape the counters were collected on
-                if (pm.get("kernel_info") == [info["tree"], info["group"], int(info["bvh"])] and pm.get("passes_per_launch") == passes_per_launch
+                if (pm.get("kernel_info") == [info["tree"], info["group"], int(info["bvh"]), info["pool"]] and pm.get("passes_per_launch") == passes_per_launch
                         and pm.get("samples_per_launch") == samples_per_launch and args.kernel == 0):
                     traffic = pm.get("hbm_bytes_per_launch")
                     valu = pm.get("valu")

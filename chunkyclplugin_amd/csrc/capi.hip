@@ -74,7 +74,7 @@ struct DevBuf {
 
 struct chunky_scene {
     chunky_ctx* ctx = nullptr;
-    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, quad_aux;
+    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, cube_info, quad_aux;
     std::vector<int32_t> host_blocks, host_materials;  // kept to rebuild block_info when either changes
     std::vector<int32_t> host_quads;                   // kept to build quad_aux
     bool quad_aux_dirty = false;
@@ -102,12 +102,13 @@ struct chunky_render {
     int kernel_variant = 0;
     ShardView shard{0, 1, 256, 0};
     DevBuf own_fb, work_counter;
+    DevBuf staging;  // render_pool: one launch's samples, [pass][pixel slot][3] floats
     float* fb = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // timing brackets of enqueued launches
     std::vector<hipEvent_t> free_events;
     float timed_ms = 0;
     int timed_launches = 0;
-    KernelChoice last_choice{0, 0, 0, 0};  // what the most recent launch ran (chunky_render_kernel_info)
+    KernelChoice last_choice{0, 0, 0, 0, -1};  // what the most recent launch ran (chunky_render_kernel_info)
     ~chunky_render() {
         for (auto& p : pending) {
             (void)hipEventDestroy(p.first);
@@ -116,6 +117,8 @@ struct chunky_render {
         for (auto e : free_events) (void)hipEventDestroy(e);
     }
 };
+
+constexpr size_t kStagingBytes = (size_t)4 << 30;  // 4 GiB: 1920x1080 x 128 passes is 3.2 GB
 
 static int n_local_slots(int n_pixels, const ShardView& t) {
     if (t.world == 1) return n_pixels;
@@ -260,6 +263,7 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
         // block_info: per block {type, pointer, 5 material words of a full cube, 0} (rt_device.hpp)
         const std::vector<int32_t>&B = scene->host_blocks, &M = scene->host_materials;
         scene->block_info.release();
+        scene->cube_info.release();
         if (!B.empty() && !M.empty()) {
             std::vector<int32_t> info((B.size() / 2) * 8, 0);
             for (size_t k = 0; k + 1 < B.size(); k += 2) {
@@ -272,6 +276,18 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
                     e[0] = 0x7FFFFFFF;  // malformed cube: an unknown model type never hits (K/block.h:44-47)
             }
             HIP_TRY(scene->block_info.upload(info.data(), info.size() * 4, scene->ctx->stream));
+            // cube_info (rt_device.hpp): the 16 bytes the full-cube test needs, for well-formed cubes without an emittance texture
+            std::vector<uint32_t> cube((B.size() / 2) * 4, 0u);
+            for (size_t k = 0; k + 1 < B.size(); k += 2) {
+                const int32_t* e = &info[(k / 2) * 8];
+                if (e[0] != 1 || (e[2] & 2)) continue;
+                uint32_t* c = &cube[(k / 2) * 4];
+                c[0] = 0x80000000u | (((uint32_t)e[6] & 0xFFu) << 8) | ((uint32_t)e[2] & 7u);
+                c[1] = (uint32_t)e[3];
+                c[2] = (uint32_t)e[4];
+                c[3] = (uint32_t)e[5];
+            }
+            HIP_TRY(scene->cube_info.upload(cube.data(), cube.size() * 4, scene->ctx->stream));
         }
     }
     return CHUNKY_OK;
@@ -485,6 +501,7 @@ static int scene_view(chunky_scene* s, SceneView* v) {
     v->quad_aux = (const float*)s->quad_aux.p;
     v->bvh_stack_entries = (s->world_height > s->actor_height ? s->world_height : s->actor_height) + 1;
     v->block_info = (const int4*)s->block_info.p;
+    v->cube_info = (const uint4*)s->cube_info.p;
     v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;
     v->wide_nlev = s->wide_meta.nlev;
     for (int i = 0; i < 6; i++) {
@@ -572,7 +589,7 @@ extern "C" int chunky_render_set_option(chunky_render* r, int option, int32_t va
             r->opts.draw_depth = value;
             break;
         case CHUNKY_OPT_MAX_DEPTH:
-            if (value < 1 || value > 5) return fail(CHUNKY_E_INVALID, "max depth must be in 1..5");
+            if (value < 1 || value > 255) return fail(CHUNKY_E_INVALID, "max depth must be in 1..255");
             r->opts.max_depth = value;
             break;
         case CHUNKY_OPT_EMITTER_SCALE: r->opts.emitter_scale = bits_to_float(value); break;
@@ -642,17 +659,31 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
     if (int rc = scene_view(r->scene, &S)) return rc;
     if (r->pending.size() > 4096)
         if (int rc = collect_timing(r)) return rc;
+    // render_pool stages every sample of a launch (12 bytes each): at most kStagingBytes of it, and fewer than 2^31 samples
+    const int n_local = r->shard.n_local > 0 ? r->shard.n_local : 1;
+    int64_t cap = (int64_t)(kStagingBytes / 12) / n_local;
+    const int64_t cap31 = ((int64_t)1 << 31) / n_local - 1;
+    if (cap > cap31) cap = cap31;
+    if (cap > kMaxPassesPerLaunch) cap = kMaxPassesPerLaunch;
+    if (cap < 1) cap = 1;
     for (int done = 0; done < n;) {
         PassSeeds ps;
-        ps.n = (n - done) < kMaxPassesPerLaunch ? (n - done) : kMaxPassesPerLaunch;
+        ps.n = (n - done) < (int)cap ? (n - done) : (int)cap;
         ps.first_spp = first_buffer_spp + done;
         memcpy(ps.seed, seeds + done, (size_t)ps.n * 4);
+        const size_t need = staging_floats(r->shard.n_local, ps.n) * sizeof(float);
+        if (r->staging.bytes < need) {  // grows to the largest launch seen; launches on the stream are ordered, so it is reused
+            HIP_TRY(hipStreamSynchronize(r->ctx->stream));
+            r->staging.release();
+            HIP_TRY(hipMalloc(&r->staging.p, need));
+            r->staging.bytes = need;
+        }
         hipEvent_t e0, e1;
         HIP_TRY(get_event(r, &e0));
         HIP_TRY(get_event(r, &e1));
         HIP_TRY(hipEventRecord(e0, r->ctx->stream));
         HIP_TRY(launch_render(r->kernel_variant, S, r->cam, r->opts, r->shard, ps, r->fb, (int*)r->work_counter.p, r->ctx->stream,
-                              &r->last_choice));
+                              &r->last_choice, (float*)r->staging.p));
         HIP_TRY(hipEventRecord(e1, r->ctx->stream));
         r->pending.emplace_back(e0, e1);
         done += ps.n;
@@ -685,13 +716,15 @@ extern "C" int chunky_render_kernel_time(chunky_render* r, float* total_ms, int*
     return CHUNKY_OK;
 }
 
-extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out4[4]) {
+extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]) {
     LOCK_RENDER(r);
-    if (!out4) return fail(CHUNKY_E_INVALID, "kernel_info: NULL output");
-    out4[0] = r->last_choice.tree;
-    out4[1] = r->last_choice.group;
-    out4[2] = r->last_choice.bvh;
-    out4[3] = r->last_choice.blocks;
+    if (!out8) return fail(CHUNKY_E_INVALID, "kernel_info: NULL output");
+    memset(out8, 0, 8 * sizeof(int32_t));
+    out8[0] = r->last_choice.tree;
+    out8[1] = r->last_choice.group;
+    out8[2] = r->last_choice.bvh;
+    out8[3] = r->last_choice.blocks;
+    out8[4] = r->last_choice.pool;
     return CHUNKY_OK;
 }
 
@@ -725,6 +758,7 @@ extern "C" int chunky_render_trace_records(chunky_render* r, int32_t seed, const
     LOCK_RENDER(r);
     if (n < 0 || (n > 0 && (!gids || !records || !counts || !radiance))) return fail(CHUNKY_E_INVALID, "trace_records: bad arguments");
     if (!r->have_camera) return fail(CHUNKY_E_STATE, "trace_records before set_camera");
+    if (2 * r->opts.max_depth > kMaxTraces) return fail(CHUNKY_E_STATE, "trace_records holds %d traces per sample: max depth must be <= %d", kMaxTraces, kMaxTraces / 2);
     if (n == 0) return CHUNKY_OK;
     for (int i = 0; i < n; i++)
         if (gids[i] < 0 || gids[i] >= r->width * r->height) return fail(CHUNKY_E_INVALID, "trace_records: gid %d outside the image", gids[i]);
@@ -764,11 +798,13 @@ extern "C" int chunky_java_random_ints(int64_t seed, int32_t* out, int n) {
     return CHUNKY_OK;
 }
 
-extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
-                                 int32_t merge_interval, chunky_post_render_fn post_render, void* user) {
+extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
+                                    int32_t merge_interval, const chunky_run_callbacks* callbacks) {
     if (!r || !r->ctx) return fail(CHUNKY_E_INVALID, "NULL render");
     if (!sample_buffer || !scene_spp) return fail(CHUNKY_E_INVALID, "render_run: NULL buffer");
     if (merge_interval < 1) merge_interval = 1024;  // OpenClPathTracingRenderer.java:158
+    const chunky_run_callbacks none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const chunky_run_callbacks& cb = callbacks ? *callbacks : none;
     const int64_t n = (int64_t)r->width * r->height * 3;
     std::vector<float> pass_buffer((size_t)n);
     JavaRandom rnd(0);                 // :95
@@ -780,9 +816,16 @@ extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_
     while (logical_spp < target_spp) { // :102
         int buffer_spp = 0;            // bufferSppReal
         int until_merge = target_spp - logical_spp < merge_interval ? target_spp - logical_spp : merge_interval;
-        bool stop = false;
-        while (buffer_spp < until_merge) {
+        bool stop = false, save = false;
+        while (buffer_spp < until_merge && !save) {
             int m = until_merge - buffer_spp < launch_passes ? until_merge - buffer_spp : launch_passes;
+            if (cb.save_event)  // a snapshot / dump due inside the next launch ends it there (:150)
+                for (int k = 1; k <= m; k++)
+                    if (cb.save_event(cb.user, logical_spp + buffer_spp + k)) {
+                        m = k;
+                        save = true;
+                        break;
+                    }
             std::vector<int32_t> seeds((size_t)m);
             for (int k = 0; k < m; k++) seeds[(size_t)k] = rnd.next_int();  // :107
             auto t0 = std::chrono::steady_clock::now();
@@ -791,18 +834,20 @@ extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_
             auto t1 = std::chrono::steady_clock::now();
             buffer_spp += m;
             *scene_spp += m;                                                 // :144
+            if (cb.progress) cb.progress(cb.user, *scene_spp);
+            if (cb.regenerate_camera) cb.regenerate_camera(cb.user);         // :146-148
             double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
             if (ms < 25.0 && launch_passes < kMaxPassesPerLaunch) launch_passes *= 2;
             if (ms > 90.0 && launch_passes > 1) launch_passes /= 2;
-            if (post_render && std::chrono::duration<double, std::milli>(t1 - last_callback).count() > 100.0) {  // :153-157
+            if (!save && cb.post_render && std::chrono::duration<double, std::milli>(t1 - last_callback).count() > 100.0) {  // :153-157
                 last_callback = t1;
-                if (post_render(user)) {
+                if (cb.post_render(cb.user)) {
                     stop = true;
                     break;
                 }
             }
         }
-        if (post_render && post_render(user)) stop = true;                   // :163
+        if (!stop && cb.post_render && cb.post_render(cb.user)) stop = true;  // :163
         if (stop && buffer_spp == 0) return fail(CHUNKY_E_ABORTED, "stopped by postRender");
         if (int rc = chunky_render_read(r, pass_buffer.data(), n)) return rc;  // :164-166
         const double sinv = 1.0 / (samp_spp + buffer_spp);                   // :169
@@ -811,10 +856,18 @@ extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_
             sample_buffer[i] = (sample_buffer[i] * a + (double)pass_buffer[(size_t)i] * b) * sinv;
         samp_spp += buffer_spp;
         logical_spp += buffer_spp;                                            // :178
+        if (cb.merged) cb.merged(cb.user, samp_spp);                          // :174-176
         if (stop) return fail(CHUNKY_E_ABORTED, "stopped by postRender");
+        if (save && cb.post_render && cb.post_render(cb.user)) return fail(CHUNKY_E_ABORTED, "stopped by postRender");  // :179-182
         // bufferSppReal = 0 (:170): the next pass runs with spp = 0, i.e. (mean*0 + c)/1 — no reset needed
     }
     return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
+                                 int32_t merge_interval, chunky_post_render_fn post_render, void* user) {
+    const chunky_run_callbacks cb{post_render, nullptr, nullptr, nullptr, nullptr, user};
+    return chunky_render_run_ex(r, sample_buffer, scene_spp, target_spp, merge_interval, &cb);
 }
 
 // ------------------------------------------------------------------------------------ wide tree hook

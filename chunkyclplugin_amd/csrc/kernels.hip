@@ -34,8 +34,13 @@ struct LdsStack {
 // where the reference descends nine — same (data, level) for every cell.
 // `kind`: 0 full cube, 1 other model, 2 or 3 cannot be hit (air, invisible, ANY_TYPE); the reference
 // layout carries no kinds, so every non-air leaf reports 1 there (the general test handles all types).
+struct TopCache {
+    int* idx;
+    int* e;
+};
 template <int TREE>
-DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind, bool inside = true) {
+DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind, bool inside = true,
+                     TopCache cache = TopCache{nullptr, nullptr}) {
     // `inside` false: the cell is not in the world; the lookup then reads cell (0, 0, 0) (callers discard it)
     if (TREE < 16 && !inside) bx = by = bz = 0;
     if (TREE == 0) {
@@ -59,7 +64,14 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
                 unsigned idx = (((((unsigned)bx >> (3 * N3)) << tb) | ((unsigned)by >> (3 * N3))) << tb) | ((unsigned)bz >> (3 * N3));
                 idx = inside ? idx : 0u;  // the levels below mask their index bits: any bx, by, bz stay inside the node
                 // byte offset in 32 bits (the builder keeps the array under 2^30 entries): SGPR base + VGPR offset
-                e = *(const int*)((const char*)tree + (idx << 2));
+                if (cache.idx) {
+                    if ((int)idx != *cache.idx) {
+                        *cache.e = *(const int*)((const char*)tree + (idx << 2));
+                        *cache.idx = (int)idx;
+                    }
+                    e = *cache.e;
+                } else
+                    e = *(const int*)((const char*)tree + (idx << 2));
             }
 #pragma unroll
             for (int i = 0; i < N3; i++) {
@@ -281,6 +293,7 @@ struct LaneState {
     // path state that is saved is one spill less; none of these is touched by the march loop.
     // pixel / pass
     int gid;
+    int sidx;              // render_pool: index of the sample in the launch (pass * n_local + pixel slot)
     unsigned pass : 8;     // pass index inside the launch (< kMaxPassesPerLaunch)
     unsigned slot : 1;     // G > 1: which open pixel of the group this lane's pass belongs to,
     unsigned serial : 23;  //        and that pixel's serial
@@ -307,6 +320,9 @@ struct LaneState {
     int bvh_head;  // first word of node bvh_cur (> 0: index of its second child; <= 0: -pointer to a leaf's triangles)
     float bvh_dist;
     f3 far;  // per axis 1.0 where the ray runs towards +axis (inv > 0), else 0.0: selects a leaf's exit plane
+    // render_pool: the top-level entry of the wide tree read last and its index (-1: none).  A third of the march steps
+    // stay inside the top cell of the step before (8^3 blocks): those skip the first of the two dependent reads
+    int top_idx, top_e;
     // main record
     Hit h;
 };
@@ -376,7 +392,7 @@ DEV bool in_mask(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 template <int TREE>
 DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneMask marching, LaneMask& cand_out,
-                    LaneMask& live_out, int& data, int& level) {
+                    LaneMask& live_out, int& data, int& level, LaneMask* model_out = nullptr, bool top_cache = false) {
     const int depth = S.octree_depth;
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
@@ -384,9 +400,16 @@ DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneM
     const bool inside = ((bx | by | bz) >> depth) == 0;
     const LaneMask live = marching & __ballot(L.steps < O.draw_depth) & __ballot(!(L.dist_march > L.h.distance)) & __ballot(inside);
     int kind;
-    leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, inside);
+    if (top_cache) {
+        int ci = L.top_idx, ce = L.top_e;  // locals: LaneState stays promotable to registers
+        leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, inside, TopCache{&ci, &ce});
+        L.top_idx = ci;
+        L.top_e = ce;
+    } else
+        leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, inside);
     const LaneMask hittable = __ballot(kind < 2);
     const LaneMask cand = live & hittable, go = live & ~hittable;
+    if (model_out) *model_out = cand & __ballot(kind == 1);  // candidates that are AABB / quad models (or of unknown kind)
     const float step = leaf_exit_distance(L, po, bx, by, bz, level) + kOffset;  // K/octree.h:103-106
     const bool advance = in_mask(go);
     L.dist_march = advance ? L.dist_march + step : L.dist_march;
@@ -395,13 +418,15 @@ DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneM
     live_out = live;
 }
 
-template <int TREE, int END>
+// CUBE: every candidate here is a full cube by the tree's leaf kind (render_pool votes cubes and models separately)
+template <int TREE, int END, bool CUBE = false>
 DEV int block_phase(const SceneView& S, LaneState& L) {
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
     int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
     Hit t = L.h;
-    float dist = block_hit(S, L.cand_data, bx, by, bz, pos, L.d, L.inv, t);
+    float dist = (CUBE && S.cube_info && S.block_info) ? block_hit_cube(S, L.cand_data, bx, by, bz, pos, L.d, L.inv, t)
+                                        : block_hit(S, L.cand_data, bx, by, bz, pos, L.d, L.inv, t);
     if (!L.shadow) {  // a rejected cube has already overwritten the normal (K/block.h:59-60)
         L.h.normal = t.normal;
         L.h.color = t.color;
@@ -561,6 +586,8 @@ struct WaveArgs {
     float* res;
     unsigned long long* stats;
     unsigned stack_bytes;  // size of the BVH-stack area at the start of dynamic LDS
+    float* staging;        // render_pool: radiance of every sample of the launch, [pass][pixel slot][3]
+    unsigned n_samples;    // render_pool: n_local * P.n
 };
 static_assert(sizeof(WaveArgs) <= 4096, "launch arguments must fit the 4 KB kernel-argument segment");
 typedef const WaveArgs __attribute__((address_space(4))) * WaveArgPtr;
@@ -1088,6 +1115,341 @@ __global__ void __launch_bounds__(256, ((BVH || STATS) ? 4 : CHUNKY_WAVES_PER_SI
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// render_pool — the wave-scheduled path state machine with a POOL of paths per wave.
+//
+// render_waves binds a path to a lane for its whole life, so the phase a wave executes only ever serves the lanes
+// that happen to wait in it (39 / 27 / 35 of 64 for MARCH / BLOCK / SHADE on the benchmark view).  Here a wave owns
+// 64 + K paths: 64 in its lanes' registers and K parked in LDS (32 dwords each: everything LaneState carries between
+// phases).  Before a phase runs, lanes whose path waits for another phase swap it for a parked path that waits for
+// this one, so the phase executes for (almost) every lane as long as the pool holds 64 such paths; nothing is shared
+// between waves and nothing waits on another wave.  The vote is over the pool, not the lanes.
+//
+// A work item is one SAMPLE (pass, pixel), claimed from a global counter in pass-major order; its radiance goes to a
+// staging array [pass][pixel][3] and fold_kernel applies the running mean of K/rayTracer.cl:109-112 in pass order
+// afterwards — the same float recurrence in the same order, so the image is bit-identical, and the pixel groups, LDS
+// rings and hand-over rounds of render_waves (15 % of its time) do not exist here.
+enum : int {
+    ST_FRESH = 12,  // the lane (or parked slot) holds no path and wants a sample; served by the SHADE branch
+    ST_MODEL = 13   // at a candidate block that is not a full cube (ST_BLOCK then means: a full cube)
+};
+
+struct PoolLds {
+    uint4* park;  // [8][K]: dword group g of slot s at park[g * K + s] (consecutive lanes, consecutive 16 bytes)
+    int* tags;    // [K] state of the path parked in slot s
+    int* list;    // [K] scratch: the slots taking part in a swap, by rank
+};
+
+DEV int phase_class(int st) { return st == ST_MARCH ? 0 : (st == ST_BLOCK ? 1 : (st == ST_DONE ? 3 : (st == ST_MODEL ? 4 : 2))); }
+
+DEV void pool_pack(const LaneState& L, uint4 (&v)[8]) {
+    const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.cand_level << 10);
+    v[0] = make_uint4((unsigned)L.sidx, L.rng, misc, (unsigned)L.steps);
+    v[1] = make_uint4(__float_as_uint(L.radiance.x), __float_as_uint(L.radiance.y), __float_as_uint(L.radiance.z), __float_as_uint(L.throughput.x));
+    v[2] = make_uint4(__float_as_uint(L.throughput.y), __float_as_uint(L.throughput.z), __float_as_uint(L.o.x), __float_as_uint(L.o.y));
+    v[3] = make_uint4(__float_as_uint(L.o.z), __float_as_uint(L.d.x), __float_as_uint(L.d.y), __float_as_uint(L.d.z));
+    v[4] = make_uint4(__float_as_uint(L.inv.x), __float_as_uint(L.inv.y), __float_as_uint(L.inv.z), __float_as_uint(L.dist_march));
+    v[5] = make_uint4(__float_as_uint(L.far.x), __float_as_uint(L.far.y), __float_as_uint(L.far.z), (unsigned)L.cand_data);
+    v[6] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
+    v[7] = make_uint4(__float_as_uint(L.h.color.x), __float_as_uint(L.h.color.y), __float_as_uint(L.h.color.z), __float_as_uint(L.h.emittance));
+}
+DEV void pool_unpack(LaneState& L, const uint4 (&v)[8]) {
+    L.sidx = (int)v[0].x; L.rng = v[0].y; L.steps = (int)v[0].w;
+    L.depth = v[0].z & 0xFFu; L.shadow = (v[0].z >> 8) & 1u; L.oct_hit = (v[0].z >> 9) & 1u; L.cand_level = (v[0].z >> 10) & 15u;
+    L.radiance = mk3(__uint_as_float(v[1].x), __uint_as_float(v[1].y), __uint_as_float(v[1].z));
+    L.throughput = mk3(__uint_as_float(v[1].w), __uint_as_float(v[2].x), __uint_as_float(v[2].y));
+    L.o = mk3(__uint_as_float(v[2].z), __uint_as_float(v[2].w), __uint_as_float(v[3].x));
+    L.d = mk3(__uint_as_float(v[3].y), __uint_as_float(v[3].z), __uint_as_float(v[3].w));
+    L.inv = mk3(__uint_as_float(v[4].x), __uint_as_float(v[4].y), __uint_as_float(v[4].z));
+    L.dist_march = __uint_as_float(v[4].w);
+    L.far = mk3(__uint_as_float(v[5].x), __uint_as_float(v[5].y), __uint_as_float(v[5].z));
+    L.cand_data = (int)v[5].w;
+    L.h.distance = __uint_as_float(v[6].x);
+    L.h.normal = mk3(__uint_as_float(v[6].y), __uint_as_float(v[6].z), __uint_as_float(v[6].w));
+    L.h.color = f4{__uint_as_float(v[7].x), __uint_as_float(v[7].y), __uint_as_float(v[7].z), 0.0f};
+    L.h.emittance = __uint_as_float(v[7].w);
+}
+
+// LDS traffic between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order; the fence keeps
+// the compiler from moving accesses of different lanes to the same word across it.
+DEV void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Lanes whose path does not wait for phase X trade it for a parked path that does (as many as both sides have).
+// Lanes that hold nothing any more (ST_DONE) give their place up first.  Returns the number of swaps.
+template <int K>
+DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) {
+    const bool done = st == ST_DONE;
+    const bool out = phase_class(st) != X;
+    const bool in = lane < K && phase_class(ptag) == X;
+    const LaneMask m_done = __ballot(done), m_out = __ballot(out && !done), m_in = __ballot(in);
+    const int n_done = __popcll(m_done), n_out = n_done + __popcll(m_out), n_in = __popcll(m_in);
+    const int n = n_out < n_in ? n_out : n_in;
+    if (n == 0) return 0;  // wave-uniform
+    const int r_in = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_in, 0u));
+    const LaneMask m_mine = done ? m_done : m_out;
+    const int r_out = (done ? 0 : n_done) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_mine, 0u));
+    if (in && r_in < n) P.list[r_in] = lane;
+    wave_lds_fence();
+    if (out && r_out < n) {
+        const int s = P.list[r_out];
+        uint4 v[8];
+        pool_pack(L, v);
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const uint4 t = P.park[g * K + s];
+            P.park[g * K + s] = v[g];
+            v[g] = t;
+        }
+        const int t_new = P.tags[s];
+        P.tags[s] = st;
+        st = t_new;
+        pool_unpack(L, v);
+        L.top_idx = -1;  // the cached top-level entry belonged to the path that left
+    }
+    wave_lds_fence();
+    if (lane < K) ptag = P.tags[lane];
+    return n;
+}
+
+#ifndef CHUNKY_POOL_WAVES
+#define CHUNKY_POOL_WAVES 5
+#endif
+#ifndef CHUNKY_POOL_REFILL
+#define CHUNKY_POOL_REFILL 16
+#endif
+#ifndef CHUNKY_MODEL_BATCH
+#define CHUNKY_MODEL_BATCH 24
+#endif
+constexpr int kModelBatch = CHUNKY_MODEL_BATCH;  // model-block candidates that share one execution of their phase
+constexpr int kPoolRefill = CHUNKY_POOL_REFILL;  // leave the march loop to refill once this many lanes are free and parked marchers exist
+constexpr int kSampleBatch = 256;                // sample indices a wave claims per atomic
+
+// stats (STATS = true), same layout as render_waves: [0..8] executions / lanes / cycles of MARCH, BLOCK, SHADE; [9..11] wave
+// lifetimes; [12] swap rounds, [13] paths swapped; [14..] parts of SHADE.
+template <int TREE, int K, bool STATS>
+__global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_pool(WaveArgs unused_by_name) {
+    constexpr int END = ST_SHADE;
+    extern __shared__ int lds[];
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    PoolLds P{nullptr, nullptr, nullptr};
+    if (K > 0) {
+        char* base = (char*)lds + wave * (K * 128 + K * 8);
+        P.park = (uint4*)base;
+        P.tags = (int*)(base + K * 128);
+        P.list = P.tags + K;
+        if (lane < K) P.tags[lane] = ST_FRESH;
+    }
+    LdsStack stack{lds, 0};  // no entity BVHs in this kernel
+    LaneState L;
+    L.h.material = 0;
+    L.h.normal = mk3(0, 0, 0);
+    L.h.color = f4{0, 0, 0, 0};
+    L.h.emittance = 0;
+    L.h.distance = 0;
+    L.cand_data = 0;
+    L.cand_level = 0;
+    L.pass = 0;
+    L.gid = -1;
+    L.sidx = 0;
+    L.top_idx = -1;
+    L.top_e = 0;
+    L.mean = mk3(0, 0, 0);
+    L.slot = 0;
+    L.serial = 0;
+    L.steps = 0;
+    L.rng = 0;
+    L.depth = 0;
+    L.shadow = false;
+    L.dist_march = 0;
+    L.radiance = mk3(0, 0, 0);
+    L.throughput = mk3(0, 0, 0);
+    L.o = L.d = L.inv = L.far = mk3(0, 0, 0);
+    L.oct_hit = false;
+    L.trace_hit = false;
+    L.bvh_cur = L.bvh_top = L.bvh_which = L.bvh_head = 0;
+    L.bvh_base = nullptr;
+    L.bvh_dist = 0;
+    unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long swap_rounds = 0, swapped = 0;
+    PartTimers parts{{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0};
+    unsigned long long t_begin = 0;
+    if (STATS) t_begin = __builtin_amdgcn_s_memtime();
+    PixelPool pool{0, 0};
+    int st = ST_FRESH;
+    int ptag = lane < K ? ST_FRESH : ST_DONE;
+    wave_lds_fence();
+    for (;;) {
+        // the pool's census: paths waiting for each phase, in lanes and parked
+        const int c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
+        const int c_block = count_lanes(st == ST_BLOCK) + count_lanes(ptag == ST_BLOCK);
+        const int c_model = count_lanes(st == ST_MODEL) + count_lanes(ptag == ST_MODEL);
+        const int c_shade = count_lanes(st == ST_SHADE || st == ST_FRESH) + count_lanes(ptag == ST_SHADE || ptag == ST_FRESH);
+        if ((c_march | c_block | c_model | c_shade) == 0) break;  // every lane and every slot is ST_DONE
+        // at most 64 paths run at once; among phases that can fill the wave SHADE and BLOCK go first (they feed the march).
+        // Model blocks (slabs, plants: loops over boxes / quads, several dependent reads each) are rare and slow: they
+        // wait until a fair number of them can share one execution, or nothing else is left.
+        const int v_march = (c_march < 64 ? c_march : 64) * kWMarch, v_block = (c_block < 64 ? c_block : 64) * kWBlock,
+                  v_shade = (c_shade < 64 ? c_shade : 64) * kWShade;
+        int X = (v_shade >= v_block && v_shade >= v_march) ? 2 : (v_block >= v_march ? 1 : 0);
+        const int v_best = X == 2 ? v_shade : (X == 1 ? v_block : v_march);
+        if (c_model >= kModelBatch || (c_model > 0 && v_best == 0)) X = 4;
+        unsigned long long t0 = 0;
+        if (STATS) t0 = __builtin_amdgcn_s_memtime();
+        if (K > 0) {
+            const int n = pool_swap<K>(P, L, st, ptag, X, lane);
+            if (STATS && n) {
+                swap_rounds += 1;
+                swapped += (unsigned long long)n;
+            }
+        }
+        if (STATS) {  // parts 4, 5, 6 of the profile: cycles in swaps, loop iterations, entries into the march loop
+            parts.t[PT_FOLD] += __builtin_amdgcn_s_memtime() - t0;
+            parts.t[PT_OPEN] += 1;
+            parts.t[PT_HANDOUT] += X == 0 ? 1 : 0;
+        }
+        int n_exec = 0;
+        if (X == 0) {
+            WaveArgPtr A = fresh_args();
+            const SceneView Sm = arg_copy(&A->S);
+            const RenderOpts Om = arg_copy(&A->O);
+            const LaneMask entered = __ballot(st == ST_MARCH);
+            int nm = __popcll(entered);
+            n_exec = nm;
+            const int parked_march = c_march - nm;  // marchers still parked after the swap
+            int nb = c_block, ne = c_shade;          // pool-wide: a candidate or an ended trace found here joins them
+            LaneMask marching = entered, to_block = 0, to_model = 0;
+            int data, level;
+            bool go_on;
+            do {
+                if (STATS) {
+                    prof[0] += 1;
+                    prof[1] += (unsigned long long)nm;
+                }
+                LaneMask cand, live, model;
+                march_step<TREE>(Sm, Om, L, marching, cand, live, data, level, &model, TREE >= 16);
+                nb += __popcll(cand & ~model);
+                ne += __popcll(marching & ~live);
+                to_block |= cand;
+                to_model |= model;
+                marching = live & ~cand;
+                nm = __popcll(marching);
+                const bool refill = K > 0 && parked_march >= kPoolRefill && 64 - nm >= kPoolRefill;
+                go_on = nm > 0 && !refill && nm * kWMarch >= (nb < 64 ? nb : 64) * kWBlock && nm * kWMarch >= (ne < 64 ? ne : 64) * kWShade;
+            } while (go_on);
+            const bool found = in_mask(to_block);
+            L.cand_data = found ? data : L.cand_data;
+            L.cand_level = found ? level : L.cand_level;
+            st = found ? (in_mask(to_model) ? ST_MODEL : ST_BLOCK) : (in_mask(entered & ~marching & ~to_block) ? END : st);
+            if (STATS) {
+                prof[0] -= 1;
+                prof[1] -= (unsigned long long)n_exec;
+            }
+        } else if (X == 1) {
+            n_exec = count_lanes(st == ST_BLOCK);
+            const SceneView S = arg_copy(&fresh_args()->S);
+            if (st == ST_BLOCK) st = block_phase<TREE, END, true>(S, L);
+        } else if (X == 4) {
+            n_exec = count_lanes(st == ST_MODEL);
+            const SceneView S = arg_copy(&fresh_args()->S);
+            if (st == ST_MODEL) st = block_phase<TREE, END>(S, L);
+        } else {
+            n_exec = count_lanes(st == ST_SHADE || st == ST_FRESH);
+            WaveArgPtr A = fresh_args();
+            const SceneView S = arg_copy(&A->S);
+            const RenderOpts O = arg_copy(&A->O);
+            if (st == ST_SHADE) st = shade_phase<TREE, false, STATS>(S, O, L, stack, &parts);
+            part_begin<STATS>(&parts);
+            if (st == ST_NEXT) {  // the path is finished: its radiance waits in the staging array for fold_kernel
+                *(f3*)(A->staging + 3 * (size_t)(unsigned)L.sidx) = L.radiance;  // one 12-byte store
+                st = ST_FRESH;
+            }
+            part_end<STATS>(&parts, PT_DEPOSIT);
+            // ---- new samples (K/rayTracer.cl:55-91), claimed in pass-major order ----
+            const bool need = st == ST_FRESH;
+            const unsigned sidx = (unsigned)claim_slot<kSampleBatch>(arg_copy(&A->Q), pool, need);  // convergent
+            if (need) {
+                const unsigned n_samples = A->n_samples;
+                if (sidx >= n_samples) {
+                    st = ST_DONE;
+                } else {
+                    const CameraView C = arg_copy(&A->C);
+                    const ShardView T = arg_copy(&A->T);
+                    const unsigned pass = sidx / (unsigned)T.n_local;
+                    const int slot = (int)(sidx - pass * (unsigned)T.n_local);
+                    const int gid = shard_gid(T, slot);
+                    if (gid < C.width * C.height) {  // else: padding of the last tile, nothing to render (the lane claims again)
+                        unsigned rng = (unsigned)A->P.seed[pass] + (unsigned)gid;
+                        rt_pcg_next(&rng);
+                        const RayOD pr = primary_ray(C, gid, rng, false);
+                        L.sidx = (int)sidx;
+                        L.rng = rng;
+                        L.o = pr.o;
+                        L.d = pr.d;
+                        L.radiance = mk3(0, 0, 0);
+                        L.throughput = mk3(1, 1, 1);
+                        L.depth = 0;
+                        L.shadow = false;
+                        L.h.distance = rt_inf();
+                        st = ST_SETUP;
+                    }
+                }
+            }
+            part_end<STATS>(&parts, PT_NEWSAMPLE);
+            if (st == ST_SETUP) st = trace_setup<END>(S, L);
+            part_end<STATS>(&parts, PT_SETUP);
+        }
+        if (STATS) {
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (X == k) {
+                    prof[3 * k] += 1;
+                    prof[3 * k + 1] += (unsigned long long)n_exec;
+                    prof[3 * k + 2] += dt;
+                }
+            if (X == 4) {  // parts 8, 9: lanes served and cycles of the model phase
+                parts.t[8] += (unsigned long long)n_exec;
+                parts.t[9] += dt;
+            }
+        }
+    }
+    if (STATS && lane == 0) {
+        unsigned long long* stats = fresh_args()->stats;
+        for (int k = 0; k < 9; k++) atomicAdd(&stats[k], prof[k]);
+        const unsigned long long life = __builtin_amdgcn_s_memtime() - t_begin;
+        atomicAdd(&stats[9], life);
+        atomicMax(&stats[10], life);
+        atomicAdd(&stats[11], 1ull);
+        atomicAdd(&stats[12], swap_rounds);
+        atomicAdd(&stats[13], swapped);
+        for (int k = 0; k < 10; k++) atomicAdd(&stats[14 + k], parts.t[k]);
+    }
+}
+
+// The running mean of K/rayTracer.cl:109-112 over the staged samples of a launch, strictly in pass order: one thread per
+// pixel and channel, reads coalesced across pixels ([pass][slot][3]).
+__global__ void __launch_bounds__(256) fold_kernel(const float* __restrict__ staging, float* __restrict__ res, ShardView T, int n_pixels,
+                                                    int n_passes, int first_spp) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = 3ll * T.n_local;
+    if (t >= n) return;
+    const int slot = (int)(t / 3), c = (int)(t - 3ll * slot);
+    const int gid = shard_gid(T, slot);
+    if (gid >= n_pixels) return;
+    float mean = res[3 * (size_t)gid + c];
+    const float* p = staging + t;
+#pragma unroll 8
+    for (int k = 0; k < n_passes; k++) {
+        const int spp = first_spp + k;
+        mean = (mean * (float)spp + p[(size_t)k * (size_t)n]) / (float)(spp + 1);
+    }
+    res[3 * (size_t)gid + c] = mean;
+}
+
 template <int TREE>
 __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraView C, RenderOpts O, int seed,
                                                              const int* __restrict__ gids, int n,
@@ -1290,8 +1652,84 @@ static size_t stack_lds_bytes(const SceneView& S, int block) {
     return need ? (size_t)entries * block * sizeof(int) : 0;
 }
 
+// render_pool + fold_kernel.  variant bits 6-7 pick the parked paths per wave: 0 = 48 (default), 1 = none, 2 = 32, 3 = 64.
+static hipError_t launch_pool(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
+                              const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
+                              float* staging) {
+    const int block = 256;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        n_cu = prop.multiProcessorCount;
+    }
+    if (T.n_local <= 0 || P.n <= 0) return hipSuccess;
+    const bool stats = (variant & 4) != 0;
+    int tree = 0;
+    if (use_wide(variant, S)) {
+        tree = S.wide_nlev <= 4 ? 16 + S.wide_nlev - 1 : -1;
+        for (int i = 1; i < S.wide_nlev; i++)
+            if (S.wide_bits[i] != 3) tree = -1;
+    }
+    int park = 48;
+    switch ((variant >> 6) & 3) {
+        case 1: park = 0; break;
+        case 2: park = 32; break;
+        case 3: park = 64; break;
+        default: break;
+    }
+    if (const char* e = getenv("CHUNKY_DEBUG_POOL")) park = atoi(e);
+    typedef void (*Kernel)(WaveArgs);
+    Kernel k;
+    if (stats) {
+        if (tree != 17) tree = -1;
+        park = 48;
+        k = tree == 17 ? render_pool<17, 48, true> : render_pool<-1, 48, true>;
+    } else if (park != 48) {
+        if (tree != 17) tree = -1;
+        if (park == 0) k = tree == 17 ? render_pool<17, 0, false> : render_pool<-1, 0, false>;
+        else if (park == 32) k = tree == 17 ? render_pool<17, 32, false> : render_pool<-1, 32, false>;
+        else { park = 64; k = tree == 17 ? render_pool<17, 64, false> : render_pool<-1, 64, false>; }
+    } else {
+        switch (tree) {
+            case 0: k = render_pool<0, 48, false>; break;
+            case 16: k = render_pool<16, 48, false>; break;
+            case 17: k = render_pool<17, 48, false>; break;
+            case 18: k = render_pool<18, 48, false>; break;
+            case 19: k = render_pool<19, 48, false>; break;
+            default: tree = -1; k = render_pool<-1, 48, false>; break;
+        }
+    }
+    const size_t lds = (size_t)(block / 64) * (size_t)(park * 128 + park * 8);
+    int occ = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
+    if (e != hipSuccess) return e;
+    const int bpc = occ > 0 ? occ : 1;
+    const long long n_samples = (long long)T.n_local * P.n;
+    // a wave keeps 64 + park paths in flight: no more workgroups than the samples can feed
+    const long long want = (n_samples + (long long)(block / 64) * (64 + park) - 1) / ((long long)(block / 64) * (64 + park));
+    int grid = n_cu * bpc;
+    if ((long long)grid > want) grid = (int)want;
+    if (chosen) *chosen = KernelChoice{tree, 1, 0, grid, park};
+    e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), 0u, staging, (unsigned)n_samples};
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long long threads = 3ll * T.n_local;
+    hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (const float*)staging, res, T,
+                       C.width * C.height, P.n, P.first_spp);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
-                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen) {
+                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
+                         float* staging) {
+    const bool any_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
+    if (!(variant & 2) && !(variant & 8) && work_counter && staging && !any_bvh)
+        return launch_pool(variant, S, C, O, T, P, res, work_counter, stream, chosen, staging);
     if (!(variant & 2) && work_counter) {
         const bool stats = (variant & 4) != 0;  // work_counter[2..] = 9 x u64 phase profile
         // wave-scheduled persistent kernel: one resident grid, lanes pull pixels from a counter
@@ -1383,17 +1821,17 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         int grid = n_cu * bpc;
         if ((long long)grid > want) grid = (int)want;
         if (grid <= 0 || P.n <= 0) return hipSuccess;
-        if (chosen) *chosen = KernelChoice{tree, group, has_bvh ? 1 : 0, grid};
+        if (chosen) *chosen = KernelChoice{tree, group, has_bvh ? 1 : 0, grid, -1};
         e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
-        WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)stack};
+        WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)stack, nullptr, 0u};
         hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
         return hipGetLastError();
     }
     const int block = 256;
     int grid = (T.n_local + block - 1) / block;
     if (grid <= 0 || P.n <= 0) return hipSuccess;
-    if (chosen) *chosen = KernelChoice{use_wide(variant, S) ? -1 : 0, 0, (!S.world_bvh_empty || !S.actor_bvh_empty) ? 1 : 0, grid};
+    if (chosen) *chosen = KernelChoice{use_wide(variant, S) ? -1 : 0, 0, any_bvh ? 1 : 0, grid, -1};
     if (use_wide(variant, S))
         hipLaunchKernelGGL(render_lanes<-1>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
     else

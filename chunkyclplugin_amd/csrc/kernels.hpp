@@ -45,11 +45,14 @@ struct KernelChoice {
     int group;   // lanes per pixel (render_waves); 0 = render_lanes (one lane per pixel for the whole launch)
     int bvh;     // entity-BVH phases compiled in
     int blocks;  // workgroups launched
+    int pool;    // render_pool: paths parked per wave beside the 64 in its lanes; -1 = another kernel
 };
+// staging floats render_pool needs for a launch of n passes over n_local pixel slots
+inline size_t staging_floats(int n_local, int n_passes) { return 3 * (size_t)n_local * (size_t)n_passes; }
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream,
-                         KernelChoice* chosen = nullptr);
+                         KernelChoice* chosen = nullptr, float* staging = nullptr);
 hipError_t launch_trace_records(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
                                 const int* gids_dev, int n, HitRecord* out, int* counts, float* radiance,
                                 hipStream_t stream);

@@ -71,6 +71,17 @@ _lib: Optional[C.CDLL] = None
 POST_RENDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
+SAVE_EVENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32)
+REGEN_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class RunCallbacks(C.Structure):
+    """chunky_run_callbacks (include/chunky_hip.h)."""
+    _fields_ = [("post_render", POST_RENDER_FN), ("progress", PROGRESS_FN), ("merged", PROGRESS_FN),
+                ("save_event", SAVE_EVENT_FN), ("regenerate_camera", REGEN_FN), ("user", C.c_void_p)]
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -112,6 +123,7 @@ def lib() -> C.CDLL:
             "chunky_render_kernel_info": [vp, vp],
             "chunky_render_trace_records": [vp, i32, vp, C.c_int, vp, vp, vp],
             "chunky_render_run": [vp, vp, C.POINTER(i32), i32, i32, POST_RENDER_FN, vp],
+            "chunky_render_run_ex": [vp, vp, C.POINTER(i32), i32, i32, C.POINTER(RunCallbacks)],
             "chunky_java_random_ints": [i64, vp, C.c_int],
             "chunky_selftest_math": [vp, C.c_int, C.c_int, vp, vp, vp],
             "chunky_filter_frame": [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_int],

@@ -184,9 +184,9 @@ class HipPathTracingRenderer:
 
     def kernel_info(self) -> dict:
         """The kernel instantiation the last launch ran: tree form, lanes per pixel, entity-BVH phases, workgroups."""
-        out = np.zeros(4, np.int32)
+        out = np.zeros(8, np.int32)
         check(native.lib().chunky_render_kernel_info(self._h, ptr(out)))
-        return {"tree": int(out[0]), "group": int(out[1]), "bvh": bool(out[2]), "blocks": int(out[3])}
+        return {"tree": int(out[0]), "group": int(out[1]), "bvh": bool(out[2]), "blocks": int(out[3]), "pool": int(out[4])}
 
     def phase_stats(self, reset: bool = True) -> dict:
         out = np.zeros(24, np.uint64)
@@ -198,6 +198,7 @@ class HipPathTracingRenderer:
         d["handover"] = {"execs": int(out[12]), "cycles": int(out[13])}
         d["parts"] = {name: int(out[14 + i]) for i, name in enumerate(
             ("sky", "sampling", "trace_setup", "deposit", "fold", "open_pixel", "hand_out", "new_sample"))}
+        d["model"] = {"lanes": int(out[22]), "cycles": int(out[23])}  # render_pool: the model-block phase
         return d
 
     def preview(self) -> np.ndarray:
@@ -220,6 +221,24 @@ class HipPathTracingRenderer:
         spp = C.c_int32(scene_spp)
         cb = native.POST_RENDER_FN((lambda _u: 1 if self.post_render() else 0) if self.post_render else 0)
         rc = native.lib().chunky_render_run(self._h, ptr(sample_buffer), C.byref(spp), target_spp, merge_interval, cb, None)
+        if rc not in (0, native.E_ABORTED):
+            check(rc)
+        return spp.value
+
+    def render_ex(self, sample_buffer: np.ndarray, scene_spp: int, target_spp: int, merge_interval: int = 1024,
+                  progress=None, merged=None, save_event=None, regenerate_camera=None) -> int:
+        """chunky_render_run_ex: the same loop with the reference's other hooks — `progress(spp)` after every launch
+        (scene.spp, :144), `merged(spp)` after every merge (:172-177), `save_event(spp) -> bool` (isSaveEvent, :150) and
+        `regenerate_camera()` between launches (:146-148).  Returns the new scene.spp."""
+        assert sample_buffer.dtype == np.float64 and sample_buffer.size == self.width * self.height * 3
+        spp = C.c_int32(scene_spp)
+        cb = native.RunCallbacks(
+            native.POST_RENDER_FN((lambda _u: 1 if self.post_render() else 0) if self.post_render else 0),
+            native.PROGRESS_FN((lambda _u, s: progress(s)) if progress else 0),
+            native.PROGRESS_FN((lambda _u, s: merged(s)) if merged else 0),
+            native.SAVE_EVENT_FN((lambda _u, s: 1 if save_event(s) else 0) if save_event else 0),
+            native.REGEN_FN((lambda _u: regenerate_camera()) if regenerate_camera else 0), None)
+        rc = native.lib().chunky_render_run_ex(self._h, ptr(sample_buffer), C.byref(spp), target_spp, merge_interval, C.byref(cb))
         if rc not in (0, native.E_ABORTED):
             check(rc)
         return spp.value

@@ -94,10 +94,12 @@ int chunky_render_set_camera(chunky_render* r, int projector_type, const float* 
 
 typedef enum chunky_option {
     CHUNKY_OPT_DRAW_DEPTH = 0,      /* int, default 256  (K/rayTracer.cl:94) */
-    CHUNKY_OPT_MAX_DEPTH = 1,       /* int, default 5    (K/rayTracer.cl:107) */
+    CHUNKY_OPT_MAX_DEPTH = 1,       /* int >= 1, default 5 (K/rayTracer.cl:107) */
     CHUNKY_OPT_EMITTER_SCALE = 2,   /* float bits, default 13.0f (K/rayTracer.cl:99) */
     CHUNKY_OPT_KERNEL = 3           /* int: kernel variant, 0 = default; bit 0 reference octree layout, bit 1 one lane
-                                     * per path, bit 2 phase profile, bits 4-5 lanes per pixel 1/8/16 (all bit-identical) */
+                                     * per path, bit 2 phase profile, bit 3 the grouped kernel instead of the pool kernel,
+                                     * bits 4-5 (grouped kernel) lanes per pixel 1/8/16, bits 6-7 (pool kernel) paths parked
+                                     * per wave none/32/64 instead of 48 (all bit-identical) */
 } chunky_option;
 int chunky_render_set_option(chunky_render* r, int option, int32_t value);
 
@@ -126,11 +128,11 @@ int chunky_render_read(chunky_render* r, float* out, int64_t n_floats);
 int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches);
 
 /* Which kernel instantiation the most recent chunky_render_passes launch ran (no reference counterpart; the parity
- * tests assert it, so that a comparison with the oracle is a comparison of the kernel that is timed): out4 =
+ * tests assert it, so that a comparison with the oracle is a comparison of the kernel that is timed): out8 =
  * {tree form: 0 reference octree layout (K/octree.h:81-89), -1 generic wide tree, 16 + n dense top node over n levels
  * of 8x8x8 nodes; lanes per pixel (0 = one lane per pixel for the whole launch); entity-BVH phases present (K/bvh.h:22-113);
- * workgroups launched}. */
-int chunky_render_kernel_info(chunky_render* r, int32_t out4[4]);
+ * workgroups launched; paths parked per wave (pool kernel; -1 = the grouped kernel); 3 reserved}. */
+int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]);
 
 /* Profile of the wave-scheduled kernel, filled only while CHUNKY_OPT_KERNEL has bit 2 set: for each of
  * the phases MARCH, BLOCK, SHADE the number of wave-level executions, the lanes active in them and
@@ -169,6 +171,33 @@ int chunky_render_trace_records(chunky_render* r, int32_t seed, const int32_t* g
 typedef int (*chunky_post_render_fn)(void* user);
 int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
                       int32_t merge_interval, chunky_post_render_fn post_render, void* user);
+
+/* The same loop with every hook the reference's loop has (any pointer may be NULL):
+ *   post_render       BooleanSupplier postRender: polled at least every 100 ms between launches and before every merge;
+ *                     non-zero stops the loop (OpenClPathTracingRenderer.java:153-157,163,181).
+ *   progress          after every launch, with the new scene.spp (the reference increments scene.spp per pass, :144).
+ *   merged            after every merge into sample_buffer, with the spp the sample buffer now holds: the place of
+ *                     scene.postProcessFrame + manager.redrawScreen (:172-177).  sample_buffer is complete and not
+ *                     touched by the library while the callback runs.
+ *   save_event        isSaveEvent(manager.getSnapshotControl(), scene, spp) (:150,193-195): non-zero means a snapshot or
+ *                     render dump is due when the scene reaches `spp`.  The loop asks for every spp the next launch
+ *                     would cover and cuts the launch there, merges at once (forced merge, :151,162-178) and polls
+ *                     post_render once more after `merged` (:179-182).
+ *   regenerate_camera between launches, for projections other than pinhole: the reference re-generates the jittered
+ *                     camera-ray table on a worker while passes run (:146-148, ClCamera.java:72-104).  The hook may
+ *                     call chunky_render_set_camera (from this or any other thread: the context mutex is the
+ *                     reference's renderLock) to install a fresh table; passes already queued finish with the old one.
+ * chunky_render_run(..., post_render, user) is chunky_render_run_ex with only post_render set. */
+typedef struct chunky_run_callbacks {
+    int (*post_render)(void* user);
+    void (*progress)(void* user, int32_t scene_spp);
+    void (*merged)(void* user, int32_t sample_spp);
+    int (*save_event)(void* user, int32_t spp);
+    void (*regenerate_camera)(void* user);
+    void* user;
+} chunky_run_callbacks;
+int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
+                         int32_t merge_interval, const chunky_run_callbacks* callbacks);
 /* The seed stream itself: first n values of new java.util.Random(seed).nextInt(). */
 int chunky_java_random_ints(int64_t seed, int32_t* out, int n);
 

@@ -39,10 +39,28 @@ public final class HipNative {
     public static native void renderSetCamera(long render, int projectorType, float[] settings);
     public static native void renderPasses(long render, int[] seeds, int firstBufferSpp);
     public static native void renderRead(long render, float[] out);
-    public static native void renderPreview(long render, int[] argbOut);
-    /** chunky_render_run: the whole pass loop; postRender is polled from native code. Returns scene.spp. */
-    public static native int renderRun(long render, double[] sampleBuffer, int sceneSpp, int targetSpp,
-                                       int mergeInterval, java.util.function.BooleanSupplier postRender);
+    /** chunky_render_preview; width/height are the render target's, the glue checks argbOut against them. */
+    public static native void renderPreview(long render, int width, int height, int[] argbOut);
+
+    /** The hooks of chunky_run_callbacks (include/chunky_hip.h) — what the loop of OpenClPathTracingRenderer.java:95-184
+     *  does on the Java side between launches. */
+    public interface RunListener {
+        /** BooleanSupplier postRender (:153-157,163,181): true stops the loop. */
+        boolean postRender();
+        /** After every launch: the new scene.spp (:144). */
+        void progress(int sceneSpp);
+        /** After every merge; the sample buffer is complete (:172-177: postProcessFrame + redrawScreen). */
+        void merged(int sampleSpp);
+        /** isSaveEvent(snapshotControl, scene, spp) (:150,193-195): a snapshot / dump is due at this spp. */
+        boolean saveEvent(int spp);
+        /** Between launches: re-generate jittered camera rays for non-pinhole projections (:146-148). */
+        void regenerateCamera();
+    }
+
+    /** chunky_render_run_ex: the whole pass loop.  sampleBuffer is read once and written at every merge (never pinned
+     *  across the run).  Returns the new scene.spp. */
+    public static native int renderRun(long render, int width, int height, double[] sampleBuffer, int sceneSpp,
+                                       int targetSpp, int mergeInterval, RunListener listener);
 
     // tone mapping — replaces the buffers + launch of GpuPostProcessingFilter.java:40-65
     public static native void filterFrame(long ctx, int width, int height, double exposure, double[] input,

@@ -1,18 +1,22 @@
 package dev.thatredox.chunkynative.hip;
 
-import dev.thatredox.chunkynative.util.Util;
+import se.llbit.chunky.main.Chunky;
 import se.llbit.chunky.renderer.DefaultRenderManager;
 import se.llbit.chunky.renderer.Renderer;
 import se.llbit.chunky.renderer.ResetReason;
-import se.llbit.chunky.renderer.scene.Camera;
+import se.llbit.chunky.renderer.SnapshotControl;
 import se.llbit.chunky.renderer.scene.Scene;
+import se.llbit.util.TaskTracker;
 
+import java.util.concurrent.ForkJoinTask;
 import java.util.function.BooleanSupplier;
 
 /**
  * Drop-in for OpenClPathTracingRenderer (J/opencl/OpenClPathTracingRenderer.java): same Renderer
  * ids, same postRender / sceneReset behaviour; the pass loop of :95-184 (seed stream, read-back every
- * <= 1024 passes, double merge) runs inside chunky_render_run.
+ * <= 1024 passes, double merge) runs inside chunky_render_run_ex and calls back here for everything the
+ * reference's loop does on the Java side: scene.spp, post-processing + redraw after a merge, snapshot / dump
+ * events, camera-ray regeneration for non-pinhole projections.
  *
  * Blind-written (no JDK / chunky-core in the build image); see INTEGRATION.md.
  */
@@ -37,16 +41,32 @@ public class HipPathTracingRenderer implements Renderer {
         Scene scene = manager.bufferedScene;
         sceneLoader.ensureLoad(scene);                                       // :64
         long render = HipNative.renderCreate(ctx, sceneLoader.handle(), scene.width, scene.height);
+        final ForkJoinTask<?>[] cameraGenTask = {Chunky.getCommonThreads().submit(() -> 0)};   // :97
         try {
-            HipCamera.apply(render, scene, true);                                    // ClCamera.java:33-104
-            int spp = HipNative.renderRun(render, scene.getSampleBuffer(), scene.spp, scene.getTargetSpp(), 1024,
-                    () -> {
-                        scene.postProcessFrame(se.llbit.util.TaskTracker.Task.NONE);  // :175-176
-                        manager.redrawScreen();
-                        return postRender.getAsBoolean();
+            HipCamera.apply(render, scene, true);                            // camera.generate(renderLock, true), :88
+            final boolean needGenerate = HipCamera.needGenerate(scene);
+            final SnapshotControl snapshots = manager.getSnapshotControl();
+            int spp = HipNative.renderRun(render, scene.width, scene.height, scene.getSampleBuffer(), scene.spp,
+                    scene.getTargetSpp(), 1024, new HipNative.RunListener() {
+                        @Override public boolean postRender() {             // :153-157 — the reference skips the poll while
+                            return !manager.shouldFinalize() && postRender.getAsBoolean();   // the manager finalizes
+                        }
+                        @Override public void progress(int sceneSpp) { scene.spp = sceneSpp; }     // :144
+                        @Override public void merged(int sampleSpp) {        // :172-177
+                            scene.postProcessFrame(TaskTracker.Task.NONE);
+                            manager.redrawScreen();
+                        }
+                        @Override public boolean saveEvent(int spp) {        // :150,193-195
+                            return scene.shouldFinalizeBuffer() || snapshots.saveSnapshot(scene, spp) || snapshots.saveRenderDump(scene, spp);
+                        }
+                        @Override public void regenerateCamera() {           // :146-148 — fresh jitter while passes run; the
+                            if (needGenerate && cameraGenTask[0].isDone())   // library's context mutex plays renderLock
+                                cameraGenTask[0] = Chunky.getCommonThreads().submit(() -> HipCamera.apply(render, scene, true));
+                        }
                     });
             scene.spp = spp;
         } finally {
+            cameraGenTask[0].join();                                         // :186
             HipNative.renderDestroy(render);
         }
     }

@@ -37,7 +37,7 @@ public class HipPreviewRenderer implements Renderer {
         long render = HipNative.renderCreate(ctx, sceneLoader.handle(), scene.width, scene.height);
         try {
             HipCamera.apply(render, scene, false);                                       // camera.generate(null, false), :72
-            HipNative.renderPreview(render, imageData);                                  // kernel launch + blocking read, :104-110
+            HipNative.renderPreview(render, scene.width, scene.height, imageData);                                 // kernel launch + blocking read, :104-110
             manager.redrawScreen();                                                      // :112
             postRender.getAsBoolean();                                                   // :113
         } finally {

@@ -10,6 +10,7 @@ import dev.thatredox.chunkynative.common.export.primitives.PackedBlock;
 import dev.thatredox.chunkynative.common.export.primitives.PackedMaterial;
 import dev.thatredox.chunkynative.common.export.primitives.PackedSun;
 import dev.thatredox.chunkynative.common.export.texture.AbstractTextureLoader;
+import dev.thatredox.chunkynative.common.state.SkyState;
 import se.llbit.chunky.renderer.ResetReason;
 import se.llbit.chunky.renderer.scene.Scene;
 
@@ -25,6 +26,7 @@ public class HipSceneLoader extends AbstractSceneLoader {
     private final long ctx;
     private long scene;
     private boolean skyLoaded = false;
+    private SkyState skyState = null;                                    // ClSceneLoader.java:28
 
     public HipSceneLoader(long ctx) {
         this.ctx = ctx;
@@ -40,9 +42,13 @@ public class HipSceneLoader extends AbstractSceneLoader {
 
     @Override
     public boolean load(int modCount, ResetReason resetReason, Scene sceneObj) {
-        if (this.modCount != modCount) {                                     // ClSceneLoader.java:40-48 (SkyState diffing
-            HipSky.upload(scene, sceneObj);                                  // is the maintainer's to keep: here the sky
-            skyLoaded = true;                                                // is re-baked whenever the scene changed)
+        if (this.modCount != modCount) {                                     // ClSceneLoader.java:40-48: the sky is baked again
+            SkyState newSky = new SkyState(sceneObj.sky(), sceneObj.sun());  // only when its state (or the sun's) changed
+            if (!newSky.equals(skyState)) {
+                HipSky.upload(scene, sceneObj);
+                skyState = newSky;
+                skyLoaded = true;
+            }
         }
         Object before = this.blockPalette;
         if (!super.load(modCount, resetReason, sceneObj)) return false;

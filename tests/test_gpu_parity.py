@@ -34,10 +34,11 @@ def assert_radiance(got, want, what):
     pytest.fail(f"{what}: within {REL_TOL} but not bit-exact ({bad} values differ) — the arithmetic contract is broken")
 
 
-# CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (wide-tree lookup),
-# bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes),
-# bits 4-5 = lanes per pixel in render_waves forced to 1 / 8 / 16 (default: chosen from the shard size)
-VARIANTS = [0, 1, 2, 3, 16, 32, 48]
+# CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (render_pool, 48 parked paths per wave, wide-tree
+# lookup), bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes),
+# bit 3 = the grouped kernel render_waves (always used for scenes with entity BVHs) with bits 4-5 = its lanes per pixel
+# forced to 1 / 8 / 16, bits 6-7 = render_pool with no / 32 / 64 parked paths
+VARIANTS = [0, 1, 2, 3, 64, 128, 192, 8, 9, 8 | 16, 8 | 32, 8 | 48]
 
 
 def make_renderer(gpu_instance, sc, variant=0):
@@ -191,7 +192,7 @@ def test_every_group_size_gives_the_same_image(gpu_instance, port, group):
     import os
     sc = gs.make("outdoor").with_view(96, 54)
     seeds = scenes.java_random_ints(64)
-    loader, r = make_renderer(gpu_instance, sc)
+    loader, r = make_renderer(gpu_instance, sc, variant=8)
     os.environ["CHUNKY_DEBUG_GROUP"] = str(group)
     try:
         r.render_passes(seeds)
@@ -343,6 +344,51 @@ def test_render_run_matches_reference_host_loop(gpu_instance, port):
     r.set_post_render(lambda: calls.append(1) or True)
     spp2 = r.render(sample, spp, spp + 100, merge_interval=interval)
     assert calls and spp2 < spp + 100
+    r.close()
+    loader.close()
+
+
+def test_render_run_ex_hooks(gpu_instance, port):
+    """chunky_render_run_ex: a save event (isSaveEvent, OpenClPathTracingRenderer.java:150) cuts the launch at its spp and
+    forces a merge there; `merged` sees every merge, `progress` every launch, `regenerate_camera` runs between launches
+    (here it installs the same pinhole camera again, :146-148).  Image = the oracle driven through the same merges."""
+    sc = gs.make("indoor").with_view(48, 32)
+    target, interval, save_at = 12, 5, 7
+    loader, r = make_renderer(gpu_instance, sc)
+    sample = np.zeros(sc.width * sc.height * 3, np.float64)
+    progress, merges, regen = [], [], []
+    spp = r.render_ex(sample, 0, target, merge_interval=interval, progress=progress.append, merged=merges.append,
+                      save_event=lambda s: s == save_at,
+                      regenerate_camera=lambda: (regen.append(1), r.set_camera(sc.projector_type, sc.camera)))
+    assert spp == target and merges == [5, 7, 12], (spp, merges)
+    assert progress == sorted(set(progress)) and progress[-1] == target and save_at in progress
+    assert len(regen) == len(progress)
+    seeds = scenes.java_random_ints(target)
+    want = np.zeros_like(sample)
+    done = 0
+    for upto in merges:
+        m = upto - done
+        pass_buf = port.render_passes(sc, seeds[done:upto]).astype(np.float64)
+        want = (want * done + pass_buf * m) * (1.0 / (done + m))
+        done = upto
+    np.testing.assert_array_equal(sample, want)
+    r.close()
+    loader.close()
+
+
+def test_max_depth_above_the_reference_constant(gpu_instance, port):
+    """CHUNKY_OPT_MAX_DEPTH is a real option: 9 bounces against the C restatement run with the same constant."""
+    from oracle.binding import PortOptions
+    sc = gs.make("indoor_sun").with_view(80, 50)
+    seeds = scenes.java_random_ints(4)
+    loader, r = make_renderer(gpu_instance, sc)
+    r.set_option(native.OPT_MAX_DEPTH, 9)
+    r.render_passes(seeds)
+    with PortOptions(port, 256, 9, 13.0):
+        want = port.render_passes(sc, seeds)
+    assert_radiance(r.read(), want, "max depth 9")
+    with pytest.raises(native.ChunkyHipError):
+        r.trace_records(1, [0])                       # the record array holds 10 traces per sample
     r.close()
     loader.close()
 

@@ -53,13 +53,14 @@ def outdoor():
 
 
 def test_headline_kernel_128_passes(gpu_instance, port, outdoor):
-    """bench.py's step: one 128-pass launch of render_waves<17, false, 8> over the whole 1080p image."""
+    """bench.py's step: one 128-pass launch of render_pool<17, 48> (+ fold_kernel) over the whole 1080p image."""
     sc = outdoor
     seeds = native.java_random_ints(128)
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
-    assert r.kernel_info() == {"tree": 17, "group": 8, "bvh": False, "blocks": r.kernel_info()["blocks"]}
-    assert r.kernel_info()["blocks"] >= 256 * 4
+    info = r.kernel_info()
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 48, False), info
+    assert info["blocks"] >= 256 * 4
     compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[::2]), "outdoor 128 passes")
     # the second step of the bench continues the running mean at bufferSpp = 128 (K/rayTracer.cl:109-112)
     more = native.java_random_ints(160)[128:]
@@ -73,18 +74,24 @@ def test_headline_kernel_128_passes(gpu_instance, port, outdoor):
     loader.close()
 
 
-@pytest.mark.parametrize("world,passes,group", [(1, 32, 8), (4, 32, 16), (8, 64, 32), (2, 48, 8)])
-def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group):
-    """The tile split of bench.py --gpus N (rank 1 of N, 256-pixel tiles): a quarter of the image runs 16 lanes per
-    pixel, an eighth 32 — the instantiations the 4- and 8-GPU lines time."""
+@pytest.mark.parametrize("world,passes,group,variant", [(1, 32, 0, 0), (4, 32, 0, 0), (8, 64, 0, 0), (2, 48, 0, 0),
+                                                        (1, 32, 8, 8), (4, 32, 16, 8), (8, 64, 32, 8)])
+def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group, variant):
+    """The tile split of bench.py --gpus N (rank 1 of N, 256-pixel tiles) with the pool kernel (a work item is a sample,
+    so every share runs the same instantiation), and with the grouped kernel (variant 8), where a quarter of the image
+    runs 16 lanes per pixel and an eighth 32."""
     sc = outdoor
     seeds = native.java_random_ints(passes)
     loader, r = make(gpu_instance, sc)
+    r.set_option(native.OPT_KERNEL, variant)
     rank = 1 if world > 1 else 0
     r.set_shard(rank, world, 256)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["group"], info["bvh"]) == (17, group, False), info
+    if variant == 0:
+        assert (info["tree"], info["pool"], info["bvh"]) == (17, 48, False), info
+    else:
+        assert (info["tree"], info["group"], info["bvh"], info["pool"]) == (17, group, False, -1), info
     own = parallel.owned_gids(sc.width * sc.height, rank, world, 256)
     rows = row_gids(sc)
     mine = np.intersect1d(rows, own)
@@ -97,20 +104,20 @@ def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group)
 
 
 def test_city_kernel(gpu_instance, port):
-    """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_waves<18, false, 8>."""
+    """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_pool<18, 48>."""
     from chunkyclplugin_amd import octree2
     sc = octree2.cached_benchmark_scene(1920, 1080)   # raises when the fixture is missing: never skipped silently
     seeds = native.java_random_ints(64)
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["group"], info["bvh"]) == (18, 8, False), info
+    assert (info["tree"], info["pool"], info["bvh"]) == (18, 48, False), info
     compare_rows(r, port, sc, seeds, row_gids(sc), "city 64 passes")
     r.set_shard(3, 8, 256)
     r.reset()
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["group"]) == (18, 32), info
+    assert (info["tree"], info["pool"]) == (18, 48), info
     own = parallel.owned_gids(sc.width * sc.height, 3, 8, 256)
     compare_rows(r, port, sc, seeds, np.intersect1d(row_gids(sc), own), "city share 1/8")
     r.close()
@@ -124,7 +131,7 @@ def test_indoor_kernel(gpu_instance, port):
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["group"], info["bvh"]) == (17, 8, False), info
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 48, False), info
     compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[1::2]), "indoor 32 passes")
     r.close()
     loader.close()
@@ -162,8 +169,9 @@ def test_entity_trace_records(gpu_instance, port, entity_world):
     gids = np.arange(1920 * 300 + 5, 1920 * 1080, 1920 * 780 // 100 + 13, dtype=np.int32)[:100]
     seed = int(native.java_random_ints(3)[2])
     rec, cnt, rad = r.trace_records(seed, gids)
-    port.counters(enable=True, reset=True)
-    port.counters(reset=True)
+    import dataclasses
+    bare = dataclasses.replace(sc, world_bvh=scenes.empty_bvh(), actor_bvh=scenes.empty_bvh())  # the same world without entities
+    touched = 0
     for i, gid in enumerate(gids):
         want, wrad = port.trace_records(sc, seed, int(gid))
         n = int(cnt[i])
@@ -176,7 +184,8 @@ def test_entity_trace_records(gpu_instance, port, entity_world):
         hit = want["hit"] == 1
         np.testing.assert_array_equal(bits(got["point"][hit]), bits(want["point"][hit]))
         np.testing.assert_array_equal(bits(rad[i]), bits(wrad))
-    c = port.counters(enable=False, reset=True)
-    assert c["tri"] > 100 and c["bvh_inner"] > 1000, f"the sample hardly exercises the BVH path: {c}"
+        w0, _ = port.trace_records(bare, seed, int(gid))
+        touched += int(len(w0) != len(want) or not np.array_equal(bits(w0["distance"]), bits(want["distance"])))
+    assert touched >= 5, f"only {touched} of {len(gids)} sampled paths meet an entity: the sample does not exercise the BVH path"
     r.close()
     loader.close()

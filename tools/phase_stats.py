@@ -34,12 +34,24 @@ samples = sc.width * sc.height * passes // world
 w = st.pop("waves")
 ho = st.pop("handover")
 parts = st.pop("parts")
-tot = sum(v["cycles"] for v in st.values())
+model = st.pop("model")
+tot = sum(v["cycles"] for v in st.values()) + model["cycles"]
 out = {"variant": variant, "launch_ms": ms / n, "Msamples/s": samples / (ms / n) / 1e3}
 for k, v in st.items():
     out[k] = {"execs_per_sample": v["execs"] * 64 / samples, "lanes_per_exec": v["lanes"] / max(v["execs"], 1),
               "cycles_per_exec": v["cycles"] / max(v["execs"], 1), "time_share": v["cycles"] / max(tot, 1)}
-out["handover"] = {"execs_per_sample": ho["execs"] * 64 / samples, "cycles_per_exec": ho["cycles"] / max(ho["execs"], 1), "share_of_total": ho["cycles"] / max(tot, 1)}
+info = r.kernel_info()
+out["kernel"] = info
+if info["pool"] >= 0:  # render_pool: the two counters are swap rounds and paths swapped
+    out["swaps"] = {"rounds_per_sample": ho["execs"] * 64 / samples, "paths_per_round": ho["cycles"] / max(ho["execs"], 1),
+                    "paths_swapped_per_sample": ho["cycles"] / samples}
+else:
+    out["handover"] = {"execs_per_sample": ho["execs"] * 64 / samples, "cycles_per_exec": ho["cycles"] / max(ho["execs"], 1), "share_of_total": ho["cycles"] / max(tot, 1)}
 out["parts_share_of_total"] = {k: round(v / max(tot, 1), 4) for k, v in parts.items()}
+if info["pool"] >= 0:  # render_pool reuses three slots: swap cycles, loop iterations, march-loop entries
+    out["parts_share_of_total"].pop("open_pixel"); out["parts_share_of_total"].pop("hand_out")
+    out["parts_share_of_total"]["swap"] = out["parts_share_of_total"].pop("fold")
+    out["model"] = {"lanes_per_64_samples": model["lanes"] * 64 / samples, "time_share": model["cycles"] / max(tot, 1)}
+    out["loop"] = {"iterations_per_64_samples": parts["open_pixel"] * 64 / samples, "march_entries_per_64_samples": parts["hand_out"] * 64 / samples}
 out["waves"] = {"n": w["n"], "mean_life_over_max": w["life_sum"] / max(w["n"], 1) / max(w["life_max"], 1)}
 print(json.dumps(out, indent=1))
