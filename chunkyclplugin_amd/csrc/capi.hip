@@ -75,9 +75,9 @@ struct DevBuf {
 struct chunky_scene {
     chunky_ctx* ctx = nullptr;
     DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, cube_info, quad_aux;
-    std::vector<int32_t> host_blocks, host_materials;  // kept to rebuild block_info when either changes
-    std::vector<int32_t> host_quads;                   // kept to build quad_aux
-    bool quad_aux_dirty = false;
+    DevBuf mat8, aabb_rec, quad_rec;                   // 16-byte-aligned re-layouts of the palettes (rt_device.hpp)
+    std::vector<int32_t> host_blocks, host_materials, host_aabbs, host_quads;  // kept to rebuild what is derived from them
+    bool derived_dirty = false;                        // block_info, cube_info, quad_aux, mat8, aabb_rec, quad_rec
     WideTree wide_meta;  // host copy kept so the kind bits can follow the block palette; nlev == 0 when absent
     bool wide_dirty = false;
     int octree_depth = -1;
@@ -255,41 +255,14 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
         default: return fail(CHUNKY_E_INVALID, "set_palette: unknown kind %d", kind);
     }
     HIP_TRY(dst->upload(data, (size_t)n * 4, scene->ctx->stream));
-    if (kind == CHUNKY_PALETTE_QUAD) scene->host_quads.assign(data, data + n);
-    if (kind == CHUNKY_PALETTE_QUAD || kind == CHUNKY_PALETTE_BLOCK) scene->quad_aux_dirty = true;
-    if (kind == CHUNKY_PALETTE_BLOCK || kind == CHUNKY_PALETTE_MATERIAL) {
-        (kind == CHUNKY_PALETTE_BLOCK ? scene->host_blocks : scene->host_materials).assign(data, data + n);
-        if (kind == CHUNKY_PALETTE_BLOCK) scene->wide_dirty = true;
-        // block_info: per block {type, pointer, 5 material words of a full cube, 0} (rt_device.hpp)
-        const std::vector<int32_t>&B = scene->host_blocks, &M = scene->host_materials;
-        scene->block_info.release();
-        scene->cube_info.release();
-        if (!B.empty() && !M.empty()) {
-            std::vector<int32_t> info((B.size() / 2) * 8, 0);
-            for (size_t k = 0; k + 1 < B.size(); k += 2) {
-                int32_t* e = &info[(k / 2) * 8];
-                e[0] = B[k];
-                e[1] = B[k + 1];
-                if (B[k] == 1 && B[k + 1] >= 0 && (size_t)B[k + 1] + 5 <= M.size())
-                    for (int w = 0; w < 5; w++) e[2 + w] = M[(size_t)B[k + 1] + w];
-                else if (B[k] == 1)
-                    e[0] = 0x7FFFFFFF;  // malformed cube: an unknown model type never hits (K/block.h:44-47)
-            }
-            HIP_TRY(scene->block_info.upload(info.data(), info.size() * 4, scene->ctx->stream));
-            // cube_info (rt_device.hpp): the 16 bytes the full-cube test needs, for well-formed cubes without an emittance texture
-            std::vector<uint32_t> cube((B.size() / 2) * 4, 0u);
-            for (size_t k = 0; k + 1 < B.size(); k += 2) {
-                const int32_t* e = &info[(k / 2) * 8];
-                if (e[0] != 1 || (e[2] & 2)) continue;
-                uint32_t* c = &cube[(k / 2) * 4];
-                c[0] = 0x80000000u | (((uint32_t)e[6] & 0xFFu) << 8) | ((uint32_t)e[2] & 7u);
-                c[1] = (uint32_t)e[3];
-                c[2] = (uint32_t)e[4];
-                c[3] = (uint32_t)e[5];
-            }
-            HIP_TRY(scene->cube_info.upload(cube.data(), cube.size() * 4, scene->ctx->stream));
-        }
+    switch (kind) {
+        case CHUNKY_PALETTE_BLOCK: scene->host_blocks.assign(data, data + n); scene->wide_dirty = true; break;
+        case CHUNKY_PALETTE_MATERIAL: scene->host_materials.assign(data, data + n); break;
+        case CHUNKY_PALETTE_AABB: scene->host_aabbs.assign(data, data + n); break;
+        case CHUNKY_PALETTE_QUAD: scene->host_quads.assign(data, data + n); break;
+        default: break;
     }
+    if (kind != CHUNKY_PALETTE_TRIG) scene->derived_dirty = true;  // rebuilt by scene_view before the next launch
     return CHUNKY_OK;
 }
 
@@ -437,6 +410,131 @@ static bool build_quad_aux(const std::vector<int32_t>& B, const std::vector<int3
     return any;
 }
 
+// Everything the kernels read that is derived from the four palettes (rt_device.hpp has the layouts):
+//   block_info  per block {type, pointer, 5 material words of a full cube, model record}
+//   cube_info   per block the 16 bytes of the full-cube test
+//   mat8        materials at a 32-byte stride (two 16-byte reads instead of five unaligned dwords)
+//   aabb_rec    AABB-model boxes as three 16-byte words each, materials as mat8 indices
+//   quad_rec    quad-model quads as six 16-byte words each (the material's five words inline), with the ray-independent values of K/primitives.h:262-276
+//               (unit normal, its dot with the origin, |xv|^2, |yv|^2) evaluated here with the kernel's own rt_math.h
+// A block whose model cannot be re-laid out (pointer outside its palette, more than 255 primitives, a material pointer
+// that is not a whole material) keeps model record 0 and takes the path that reads the packed palettes as they are.
+static int rebuild_derived(chunky_scene* s) {
+    const std::vector<int32_t>&B = s->host_blocks, &M = s->host_materials, &A = s->host_aabbs, &Q = s->host_quads;
+    hipStream_t st = s->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(st));  // queued passes may still read the old copies
+    s->block_info.release();
+    s->cube_info.release();
+    s->quad_aux.release();
+    s->mat8.release();
+    s->aabb_rec.release();
+    s->quad_rec.release();
+    s->derived_dirty = false;
+    if (B.empty() || M.empty()) return CHUNKY_OK;
+    const size_t n_blocks = B.size() / 2, n_mats = M.size() / 6;
+    std::vector<int32_t> mat8(n_mats * 8, 0);
+    for (size_t m = 0; m < n_mats; m++)
+        for (int w = 0; w < 5; w++) mat8[m * 8 + w] = M[m * 6 + w];
+    auto mat_index = [&](int32_t ptr, int32_t* out) {  // packed material pointer -> index of its first 16-byte word in mat8
+        if (ptr < 0 || ptr % 6 != 0 || (size_t)ptr / 6 >= n_mats) return false;
+        *out = (ptr / 6) * 2;
+        return true;
+    };
+    std::vector<int32_t> info(n_blocks * 8, 0), aabb_rec, quad_rec;
+    std::vector<uint32_t> cube(n_blocks * 4, 0u);
+    std::vector<int64_t> aabb_at(A.size(), -1), quad_at(Q.size(), -1);  // model pointer -> first record (models are shared between blocks)
+    for (size_t k = 0; k < n_blocks; k++) {
+        int32_t* e = &info[k * 8];
+        const int32_t type = B[2 * k], ptr = B[2 * k + 1];
+        e[0] = type;
+        e[1] = ptr;
+        if (type == 1) {
+            if (ptr >= 0 && (size_t)ptr + 5 <= M.size()) {
+                for (int w = 0; w < 5; w++) e[2 + w] = M[(size_t)ptr + w];
+                if (!(e[2] & 2)) {  // no emittance texture: the 16-byte form carries everything
+                    uint32_t* c = &cube[k * 4];
+                    c[0] = 0x80000000u | (((uint32_t)e[6] & 0xFFu) << 8) | ((uint32_t)e[2] & 7u);
+                    c[1] = (uint32_t)e[3];
+                    c[2] = (uint32_t)e[4];
+                    c[3] = (uint32_t)e[5];
+                }
+            } else {
+                e[0] = 0x7FFFFFFF;  // malformed cube: an unknown model type never hits (K/block.h:44-47)
+            }
+        } else if (type == 2 && ptr >= 0 && (size_t)ptr < A.size()) {
+            const int64_t count = A[(size_t)ptr];
+            if (count < 1 || count > 255 || (size_t)(ptr + 1 + 13 * count) > A.size()) continue;
+            if (aabb_at[(size_t)ptr] < 0) {
+                const int64_t first = (int64_t)aabb_rec.size() / 12;
+                bool ok = true;
+                std::vector<int32_t> rec((size_t)count * 12);
+                for (int64_t i = 0; i < count && ok; i++) {
+                    const int32_t* b = &A[(size_t)(ptr + 1 + 13 * i)];
+                    int32_t* r = &rec[(size_t)i * 12];
+                    for (int w = 0; w < 7; w++) r[w] = b[w];  // six bounds, flags
+                    for (int w = 0; w < 5 && ok; w++) ok = mat_index(b[8 + w], &r[7 + w]);  // E, S, W, T, B (N is never read: K/primitives.h:209-234)
+                }
+                if (!ok) {
+                    aabb_at[(size_t)ptr] = -2;
+                } else {
+                    aabb_at[(size_t)ptr] = first;
+                    aabb_rec.insert(aabb_rec.end(), rec.begin(), rec.end());
+                }
+            }
+            if (aabb_at[(size_t)ptr] >= 0 && aabb_at[(size_t)ptr] < (1 << 22)) e[7] = (int32_t)((aabb_at[(size_t)ptr] << 8) | count);
+        } else if (type == 3 && ptr >= 0 && (size_t)ptr < Q.size()) {
+            const int64_t count = Q[(size_t)ptr];
+            if (count < 1 || count > 255 || (size_t)(ptr + 1 + 15 * count) > Q.size()) continue;
+            if (quad_at[(size_t)ptr] < 0) {
+                const int64_t first = (int64_t)quad_rec.size() / 24;
+                bool ok = true;
+                std::vector<int32_t> rec((size_t)count * 24);
+                for (int64_t i = 0; i < count && ok; i++) {
+                    const int32_t* q = &Q[(size_t)(ptr + 1 + 15 * i)];
+                    float f[9];
+                    memcpy(f, q, sizeof f);
+                    const float cx = rt_cross_c(f[4], f[8], f[5], f[7]), cy = rt_cross_c(f[5], f[6], f[3], f[8]),
+                                cz = rt_cross_c(f[3], f[7], f[4], f[6]);
+                    const float rl = rt_rlen3(cx, cy, cz);
+                    const float nx = cx * rl, ny = cy * rl, nz = cz * rl;
+                    const float aux[6] = {nx, ny, nz, rt_dot3(nx, ny, nz, f[0], f[1], f[2]), rt_dot3(f[3], f[4], f[5], f[3], f[4], f[5]),
+                                          rt_dot3(f[6], f[7], f[8], f[6], f[7], f[8])};
+                    int32_t a[6];
+                    memcpy(a, aux, sizeof a);
+                    int32_t* r = &rec[(size_t)i * 24];
+                    r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = a[3];      // origin, dot(n, origin)
+                    r[4] = q[3]; r[5] = q[4]; r[6] = q[5]; r[7] = a[4];      // xv, |xv|^2
+                    r[8] = q[6]; r[9] = q[7]; r[10] = q[8]; r[11] = a[5];    // yv, |yv|^2
+                    r[12] = q[9]; r[13] = q[10]; r[14] = q[11]; r[15] = q[12];  // uv
+                    r[16] = a[0]; r[17] = a[1]; r[18] = a[2];                // unit normal
+                    int32_t m8 = 0;
+                    ok = mat_index(q[13], &m8);                              // the quad's material, inline: one dependent read less
+                    if (ok) {
+                        const int32_t* m = &M[(size_t)q[13]];
+                        r[19] = m[4];
+                        r[20] = m[0]; r[21] = m[1]; r[22] = m[2]; r[23] = m[3];
+                    }
+                }
+                if (!ok) {
+                    quad_at[(size_t)ptr] = -2;
+                } else {
+                    quad_at[(size_t)ptr] = first;
+                    quad_rec.insert(quad_rec.end(), rec.begin(), rec.end());
+                }
+            }
+            if (quad_at[(size_t)ptr] >= 0 && quad_at[(size_t)ptr] < (1 << 22)) e[7] = (int32_t)((quad_at[(size_t)ptr] << 8) | count);
+        }
+    }
+    HIP_TRY(s->block_info.upload(info.data(), info.size() * 4, st));
+    HIP_TRY(s->cube_info.upload(cube.data(), cube.size() * 4, st));
+    HIP_TRY(s->mat8.upload(mat8.data(), mat8.size() * 4, st));
+    if (!aabb_rec.empty()) HIP_TRY(s->aabb_rec.upload(aabb_rec.data(), aabb_rec.size() * 4, st));
+    if (!quad_rec.empty()) HIP_TRY(s->quad_rec.upload(quad_rec.data(), quad_rec.size() * 4, st));
+    std::vector<float> aux;  // for quads that kept the packed path
+    if (build_quad_aux(B, Q, &aux)) HIP_TRY(s->quad_aux.upload(aux.data(), aux.size() * 4, st));
+    return CHUNKY_OK;
+}
+
 // Assemble the kernel-side view; Sun_new (K/sky.h:19-40) is evaluated here, on the host, with the
 // same rt_math.h the device uses.
 static int scene_view(chunky_scene* s, SceneView* v) {
@@ -491,17 +589,15 @@ static int scene_view(chunky_scene* s, SceneView* v) {
         HIP_TRY(s->wide.upload(s->wide_meta.data.data(), s->wide_meta.data.size() * 4, s->ctx->stream));
         s->wide_dirty = false;
     }
-    if (s->quad_aux_dirty) {
-        std::vector<float> aux;
-        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-        s->quad_aux.release();
-        if (build_quad_aux(s->host_blocks, s->host_quads, &aux)) HIP_TRY(s->quad_aux.upload(aux.data(), aux.size() * 4, s->ctx->stream));
-        s->quad_aux_dirty = false;
-    }
+    if (s->derived_dirty)
+        if (int rc = rebuild_derived(s)) return rc;
     v->quad_aux = (const float*)s->quad_aux.p;
     v->bvh_stack_entries = (s->world_height > s->actor_height ? s->world_height : s->actor_height) + 1;
     v->block_info = (const int4*)s->block_info.p;
     v->cube_info = (const uint4*)s->cube_info.p;
+    v->mat8 = (const int4*)s->mat8.p;
+    v->aabb_rec = (const int4*)s->aabb_rec.p;
+    v->quad_rec = (const int4*)s->quad_rec.p;
     v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;
     v->wide_nlev = s->wide_meta.nlev;
     for (int i = 0; i < 6; i++) {

@@ -342,28 +342,31 @@ DEV int floor_to_int(float x) {
 // one with the plane the ray leaves through — max if inv > 0, else min — and only that one is evaluated
 // (L.far selects it; the fma is exact).  The one case where that product is NaN while the reference's fmax
 // returns the other one (p == min with inv == -inf: NaN against -inf) is restored by the fmax with -inf.
-DEV float leaf_exit_distance(const LaneState& L, f3 po, int bx, int by, int bz, int level) {
+DEV float leaf_exit_distance(const LaneState& L, f3 far, f3 po, int bx, int by, int bz, int level) {
     const int keep = -1 << level;
     const float size = __builtin_ldexpf(1.0f, level);
     const float x0 = (float)(bx & keep), y0 = (float)(by & keep), z0 = (float)(bz & keep);
-    const float tx = rt_fmax((rt_fma(L.far.x, size, x0) - po.x) * L.inv.x, -rt_inf());
-    const float ty = rt_fmax((rt_fma(L.far.y, size, y0) - po.y) * L.inv.y, -rt_inf());
-    const float tz = rt_fmax((rt_fma(L.far.z, size, z0) - po.z) * L.inv.z, -rt_inf());
+    const float tx = rt_fmax((rt_fma(far.x, size, x0) - po.x) * L.inv.x, -rt_inf());
+    const float ty = rt_fmax((rt_fma(far.y, size, y0) - po.y) * L.inv.y, -rt_inf());
+    const float tz = rt_fmax((rt_fma(far.z, size, z0) - po.z) * L.inv.z, -rt_inf());
     return rt_fmin(tx, rt_fmin(ty, tz));
 }
+// 1.0 per axis where the ray runs towards +axis: render_waves keeps it in LaneState.far, render_pool derives it from
+// the sign of inv where it is needed (three registers less to carry and to park)
+DEV f3 far_of(const f3& inv) { return mk3(inv.x > 0 ? 1.0f : 0.0f, inv.y > 0 ? 1.0f : 0.0f, inv.z > 0 ? 1.0f : 0.0f); }
 
-template <int TREE>
+template <int TREE, bool FARREG = true>
 DEV void leaf_exit(const SceneView& S, LaneState& L, f3 po, int bx, int by, int bz, int level) {
-    L.dist_march += leaf_exit_distance(L, po, bx, by, bz, level) + kOffset;
+    L.dist_march += leaf_exit_distance(L, FARREG ? L.far : far_of(L.inv), po, bx, by, bz, level) + kOffset;
     L.steps += 1;
 }
 
 // Start of Octree_octreeIntersect (K/octree.h:44-64): returns the next state.
-template <int END>
+template <int END, bool FARREG = true>
 DEV int trace_setup(const SceneView& S, LaneState& L) {
     const int depth = S.octree_depth;
     L.inv = rcp3(L.d);
-    L.far = mk3(L.inv.x > 0 ? 1.0f : 0.0f, L.inv.y > 0 ? 1.0f : 0.0f, L.inv.z > 0 ? 1.0f : 0.0f);
+    if (FARREG) L.far = far_of(L.inv);
     L.dist_march = 0;
     L.steps = 0;
     L.oct_hit = false;
@@ -392,7 +395,8 @@ DEV bool in_mask(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 template <int TREE>
 DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneMask marching, LaneMask& cand_out,
-                    LaneMask& live_out, int& data, int& level, LaneMask* model_out = nullptr, bool top_cache = false) {
+                    LaneMask& live_out, int& data, int& level, LaneMask* model_out = nullptr, bool top_cache = false,
+                    const LaneMask* far_masks = nullptr) {
     const int depth = S.octree_depth;
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
@@ -410,7 +414,10 @@ DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneM
     const LaneMask hittable = __ballot(kind < 2);
     const LaneMask cand = live & hittable, go = live & ~hittable;
     if (model_out) *model_out = cand & __ballot(kind == 1);  // candidates that are AABB / quad models (or of unknown kind)
-    const float step = leaf_exit_distance(L, po, bx, by, bz, level) + kOffset;  // K/octree.h:103-106
+    // render_pool passes the three lane masks "inv > 0" (scalar registers, set when the loop is entered) instead of L.far
+    const f3 far = far_masks ? mk3(in_mask(far_masks[0]) ? 1.0f : 0.0f, in_mask(far_masks[1]) ? 1.0f : 0.0f, in_mask(far_masks[2]) ? 1.0f : 0.0f)
+                             : L.far;
+    const float step = leaf_exit_distance(L, far, po, bx, by, bz, level) + kOffset;  // K/octree.h:103-106
     const bool advance = in_mask(go);
     L.dist_march = advance ? L.dist_march + step : L.dist_march;
     L.steps = advance ? L.steps + 1 : L.steps;
@@ -419,7 +426,7 @@ DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneM
 }
 
 // CUBE: every candidate here is a full cube by the tree's leaf kind (render_pool votes cubes and models separately)
-template <int TREE, int END, bool CUBE = false>
+template <int TREE, int END, bool CUBE = false, bool FARREG = true>
 DEV int block_phase(const SceneView& S, LaneState& L) {
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
@@ -440,7 +447,7 @@ DEV int block_phase(const SceneView& S, LaneState& L) {
         L.oct_hit = true;
         return END;
     }
-    leaf_exit<TREE>(S, L, po, bx, by, bz, L.cand_level);
+    leaf_exit<TREE, FARREG>(S, L, po, bx, by, bz, L.cand_level);
     return ST_MARCH;
 }
 
@@ -1149,7 +1156,7 @@ DEV void pool_pack(const LaneState& L, uint4 (&v)[8]) {
     v[2] = make_uint4(__float_as_uint(L.throughput.y), __float_as_uint(L.throughput.z), __float_as_uint(L.o.x), __float_as_uint(L.o.y));
     v[3] = make_uint4(__float_as_uint(L.o.z), __float_as_uint(L.d.x), __float_as_uint(L.d.y), __float_as_uint(L.d.z));
     v[4] = make_uint4(__float_as_uint(L.inv.x), __float_as_uint(L.inv.y), __float_as_uint(L.inv.z), __float_as_uint(L.dist_march));
-    v[5] = make_uint4(__float_as_uint(L.far.x), __float_as_uint(L.far.y), __float_as_uint(L.far.z), (unsigned)L.cand_data);
+    v[5] = make_uint4(0u, 0u, 0u, (unsigned)L.cand_data);
     v[6] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
     v[7] = make_uint4(__float_as_uint(L.h.color.x), __float_as_uint(L.h.color.y), __float_as_uint(L.h.color.z), __float_as_uint(L.h.emittance));
 }
@@ -1162,7 +1169,6 @@ DEV void pool_unpack(LaneState& L, const uint4 (&v)[8]) {
     L.d = mk3(__uint_as_float(v[3].y), __uint_as_float(v[3].z), __uint_as_float(v[3].w));
     L.inv = mk3(__uint_as_float(v[4].x), __uint_as_float(v[4].y), __uint_as_float(v[4].z));
     L.dist_march = __uint_as_float(v[4].w);
-    L.far = mk3(__uint_as_float(v[5].x), __uint_as_float(v[5].y), __uint_as_float(v[5].z));
     L.cand_data = (int)v[5].w;
     L.h.distance = __uint_as_float(v[6].x);
     L.h.normal = mk3(__uint_as_float(v[6].y), __uint_as_float(v[6].z), __uint_as_float(v[6].w));
@@ -1180,6 +1186,11 @@ DEV void wave_lds_fence() {
 
 // Lanes whose path does not wait for phase X trade it for a parked path that does (as many as both sides have).
 // Lanes that hold nothing any more (ST_DONE) give their place up first.  Returns the number of swaps.
+//
+// The state tags of the parked paths live in registers (`ptag` of lane j = tag of slot j).  Partners find each other by
+// rank through two small LDS arrays — slot and tag of the r-th parked path that comes in, tag of the r-th lane path that
+// goes out — written by everybody first and read after ONE fence; then each swapping lane reads its partner's eight
+// 16-byte groups in one burst and writes its own over them.
 template <int K>
 DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) {
     const bool done = st == ST_DONE;
@@ -1192,34 +1203,47 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
     const int r_in = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_in, 0u));
     const LaneMask m_mine = done ? m_done : m_out;
     const int r_out = (done ? 0 : n_done) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_mine, 0u));
-    if (in && r_in < n) P.list[r_in] = lane;
+    const bool comes = in && r_in < n, goes = out && r_out < n;
+    if (comes) P.list[r_in] = lane | (ptag << 8);  // slot and tag of the r-th path that comes in
+    if (goes) P.tags[r_out] = st;                  // tag of the r-th path that goes out
     wave_lds_fence();
-    if (out && r_out < n) {
-        const int s = P.list[r_out];
-        uint4 v[8];
-        pool_pack(L, v);
+    if (comes) ptag = P.tags[r_in];
+    if (goes) {
+        const int e = P.list[r_out];
+        const int s = e & 0xFF;
+        uint4 mine[8], theirs[8];
+        pool_pack(L, mine);
 #pragma unroll
-        for (int g = 0; g < 8; g++) {
-            const uint4 t = P.park[g * K + s];
-            P.park[g * K + s] = v[g];
-            v[g] = t;
-        }
-        const int t_new = P.tags[s];
-        P.tags[s] = st;
-        st = t_new;
-        pool_unpack(L, v);
+        for (int g = 0; g < 8; g++) theirs[g] = P.park[g * K + s];
+#pragma unroll
+        for (int g = 0; g < 8; g++) P.park[g * K + s] = mine[g];
+        st = e >> 8;
+        pool_unpack(L, theirs);
         L.top_idx = -1;  // the cached top-level entry belonged to the path that left
     }
-    wave_lds_fence();
-    if (lane < K) ptag = P.tags[lane];
+    wave_lds_fence();  // the next swap's readers (other lanes) come after these writes
     return n;
 }
 
 #ifndef CHUNKY_POOL_WAVES
-#define CHUNKY_POOL_WAVES 5
+#define CHUNKY_POOL_WAVES 6  // waves per SIMD: the march is bound by the latency of its two dependent tree reads, every wave counts
 #endif
+#ifndef CHUNKY_POOL_PARK
+#define CHUNKY_POOL_PARK 48  // paths parked per wave (LDS: 136 bytes each)
+#endif
+constexpr int kPoolPark = CHUNKY_POOL_PARK;
 #ifndef CHUNKY_POOL_REFILL
-#define CHUNKY_POOL_REFILL 16
+#define CHUNKY_POOL_REFILL 24
+#endif
+#ifndef CHUNKY_NT
+#define CHUNKY_NT 1  // staging array written / read with non-temporal accesses
+#endif
+#ifndef CHUNKY_TOP_CACHE
+#define CHUNKY_TOP_CACHE 0  // 1: keep the last top-level tree entry per lane (measured: no gain — a wave waits for its slowest lane)
+#endif
+#ifndef CHUNKY_POOL_SPLIT
+#define CHUNKY_POOL_SPLIT 0  // 1: full cubes and model blocks are voted as separate phases (measured: the model paths that
+                             // wait for company shrink the pool by more than the cheaper cube phase gains)
 #endif
 #ifndef CHUNKY_MODEL_BATCH
 #define CHUNKY_MODEL_BATCH 24
@@ -1241,7 +1265,6 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
         P.park = (uint4*)base;
         P.tags = (int*)(base + K * 128);
         P.list = P.tags + K;
-        if (lane < K) P.tags[lane] = ST_FRESH;
     }
     LdsStack stack{lds, 0};  // no entity BVHs in this kernel
     LaneState L;
@@ -1320,30 +1343,35 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
             int nm = __popcll(entered);
             n_exec = nm;
             const int parked_march = c_march - nm;  // marchers still parked after the swap
-            int nb = c_block, ne = c_shade;          // pool-wide: a candidate or an ended trace found here joins them
+            // The wave stays in the march while it runs fuller than anything else could: lanes that leave join the paths
+            // waiting for BLOCK or SHADE (`other` of them already), so it leaves once nm would drop below the larger of those
+            // crowds — at worst every leaver joins it: nm < other + (n0 - nm) — or once enough lanes are free for a refill
+            // from the parked marchers.  One bound, fixed on entry: the loop's bookkeeping is one popcount and one compare.
+            const int other_b = c_block < 64 ? c_block : 64, other_s = c_shade < 64 ? c_shade : 64;
+            const int other = other_b > other_s ? other_b : other_s;
+            int stay = (other + nm + 1) >> 1;
+            if (K > 0 && parked_march >= kPoolRefill && stay < 65 - kPoolRefill) stay = 65 - kPoolRefill;
+            if (stay < 1) stay = 1;
             LaneMask marching = entered, to_block = 0, to_model = 0;
+            const LaneMask far_masks[3] = {__ballot(L.inv.x > 0), __ballot(L.inv.y > 0), __ballot(L.inv.z > 0)};
             int data, level;
-            bool go_on;
             do {
                 if (STATS) {
                     prof[0] += 1;
                     prof[1] += (unsigned long long)nm;
                 }
                 LaneMask cand, live, model;
-                march_step<TREE>(Sm, Om, L, marching, cand, live, data, level, &model, TREE >= 16);
-                nb += __popcll(cand & ~model);
-                ne += __popcll(marching & ~live);
+                march_step<TREE>(Sm, Om, L, marching, cand, live, data, level, CHUNKY_POOL_SPLIT ? &model : nullptr,
+                                 CHUNKY_TOP_CACHE && TREE >= 16, far_masks);
                 to_block |= cand;
-                to_model |= model;
+                if (CHUNKY_POOL_SPLIT) to_model |= model;
                 marching = live & ~cand;
                 nm = __popcll(marching);
-                const bool refill = K > 0 && parked_march >= kPoolRefill && 64 - nm >= kPoolRefill;
-                go_on = nm > 0 && !refill && nm * kWMarch >= (nb < 64 ? nb : 64) * kWBlock && nm * kWMarch >= (ne < 64 ? ne : 64) * kWShade;
-            } while (go_on);
+            } while (nm >= stay);
             const bool found = in_mask(to_block);
             L.cand_data = found ? data : L.cand_data;
             L.cand_level = found ? level : L.cand_level;
-            st = found ? (in_mask(to_model) ? ST_MODEL : ST_BLOCK) : (in_mask(entered & ~marching & ~to_block) ? END : st);
+            st = found ? ((CHUNKY_POOL_SPLIT && in_mask(to_model)) ? ST_MODEL : ST_BLOCK) : (in_mask(entered & ~marching & ~to_block) ? END : st);
             if (STATS) {
                 prof[0] -= 1;
                 prof[1] -= (unsigned long long)n_exec;
@@ -1351,11 +1379,11 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
         } else if (X == 1) {
             n_exec = count_lanes(st == ST_BLOCK);
             const SceneView S = arg_copy(&fresh_args()->S);
-            if (st == ST_BLOCK) st = block_phase<TREE, END, true>(S, L);
+            if (st == ST_BLOCK) st = block_phase<TREE, END, CHUNKY_POOL_SPLIT != 0, false>(S, L);
         } else if (X == 4) {
             n_exec = count_lanes(st == ST_MODEL);
             const SceneView S = arg_copy(&fresh_args()->S);
-            if (st == ST_MODEL) st = block_phase<TREE, END>(S, L);
+            if (st == ST_MODEL) st = block_phase<TREE, END, false, false>(S, L);
         } else {
             n_exec = count_lanes(st == ST_SHADE || st == ST_FRESH);
             WaveArgPtr A = fresh_args();
@@ -1364,7 +1392,15 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
             if (st == ST_SHADE) st = shade_phase<TREE, false, STATS>(S, O, L, stack, &parts);
             part_begin<STATS>(&parts);
             if (st == ST_NEXT) {  // the path is finished: its radiance waits in the staging array for fold_kernel
-                *(f3*)(A->staging + 3 * (size_t)(unsigned)L.sidx) = L.radiance;  // one 12-byte store
+                // streamed past the caches (nt): written once, read once by fold_kernel; the L2 stays with the tree
+                float* __restrict__ out = A->staging + 3 * (size_t)(unsigned)L.sidx;
+#if CHUNKY_NT
+                __builtin_nontemporal_store(L.radiance.x, out);
+                __builtin_nontemporal_store(L.radiance.y, out + 1);
+                __builtin_nontemporal_store(L.radiance.z, out + 2);
+#else
+                *(f3*)out = L.radiance;
+#endif
                 st = ST_FRESH;
             }
             part_end<STATS>(&parts, PT_DEPOSIT);
@@ -1399,7 +1435,7 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
                 }
             }
             part_end<STATS>(&parts, PT_NEWSAMPLE);
-            if (st == ST_SETUP) st = trace_setup<END>(S, L);
+            if (st == ST_SETUP) st = trace_setup<END, false>(S, L);
             part_end<STATS>(&parts, PT_SETUP);
         }
         if (STATS) {
@@ -1445,7 +1481,11 @@ __global__ void __launch_bounds__(256) fold_kernel(const float* __restrict__ sta
 #pragma unroll 8
     for (int k = 0; k < n_passes; k++) {
         const int spp = first_spp + k;
+#if CHUNKY_NT
+        mean = (mean * (float)spp + __builtin_nontemporal_load(p + (size_t)k * (size_t)n)) / (float)(spp + 1);
+#else
         mean = (mean * (float)spp + p[(size_t)k * (size_t)n]) / (float)(spp + 1);
+#endif
     }
     res[3 * (size_t)gid + c] = mean;
 }
@@ -1672,7 +1712,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
         for (int i = 1; i < S.wide_nlev; i++)
             if (S.wide_bits[i] != 3) tree = -1;
     }
-    int park = 48;
+    int park = kPoolPark;
     switch ((variant >> 6) & 3) {
         case 1: park = 0; break;
         case 2: park = 32; break;
@@ -1684,21 +1724,21 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     Kernel k;
     if (stats) {
         if (tree != 17) tree = -1;
-        park = 48;
-        k = tree == 17 ? render_pool<17, 48, true> : render_pool<-1, 48, true>;
-    } else if (park != 48) {
+        park = kPoolPark;
+        k = tree == 17 ? render_pool<17, kPoolPark, true> : render_pool<-1, kPoolPark, true>;
+    } else if (park != kPoolPark) {
         if (tree != 17) tree = -1;
         if (park == 0) k = tree == 17 ? render_pool<17, 0, false> : render_pool<-1, 0, false>;
         else if (park == 32) k = tree == 17 ? render_pool<17, 32, false> : render_pool<-1, 32, false>;
         else { park = 64; k = tree == 17 ? render_pool<17, 64, false> : render_pool<-1, 64, false>; }
     } else {
         switch (tree) {
-            case 0: k = render_pool<0, 48, false>; break;
-            case 16: k = render_pool<16, 48, false>; break;
-            case 17: k = render_pool<17, 48, false>; break;
-            case 18: k = render_pool<18, 48, false>; break;
-            case 19: k = render_pool<19, 48, false>; break;
-            default: tree = -1; k = render_pool<-1, 48, false>; break;
+            case 0: k = render_pool<0, kPoolPark, false>; break;
+            case 16: k = render_pool<16, kPoolPark, false>; break;
+            case 17: k = render_pool<17, kPoolPark, false>; break;
+            case 18: k = render_pool<18, kPoolPark, false>; break;
+            case 19: k = render_pool<19, kPoolPark, false>; break;
+            default: tree = -1; k = render_pool<-1, kPoolPark, false>; break;
         }
     }
     const size_t lds = (size_t)(block / 64) * (size_t)(park * 128 + park * 8);

@@ -81,6 +81,14 @@ struct SceneView {
     // flags, tint, textureSize, color} — K/block.h:48-65 with K/material.h:31-40 as ONE 16-byte read.  valid = 0 for
     // blocks that are not well-formed cubes or whose material uses an emittance texture (those take the general path).
     const uint4* __restrict__ cube_info;
+    // 16-byte-aligned re-layouts built at upload (capi.hip rebuild_derived); block_info word 7 of a model block =
+    // first record << 8 | primitive count, 0 = none (the packed palettes are read as they are):
+    //   mat8      per material two words {flags, tint, textureSize, color} {normal_emittance, 0, 0, 0}
+    //   aabb_rec  per box three words {xmin, xmax, ymin, ymax} {zmin, zmax, flags, E} {S, W, T, B} (materials = mat8 indices)
+    //   quad_rec  per quad six words {o, dot(n, o)} {xv, |xv|^2} {yv, |yv|^2} {uv} {n, normal_emittance} {flags, tint, textureSize, color}
+    const int4* __restrict__ mat8;
+    const int4* __restrict__ aabb_rec;
+    const int4* __restrict__ quad_rec;
 };
 
 struct CameraView {
@@ -315,6 +323,76 @@ DEV float quad_model_hit(const SceneView& S, int ptr, f3 no, f3 dir, Hit& h) {
     return hit ? best : rt_nan();
 }
 
+DEV bool material_sample8(const SceneView& S, int m8, float u, float v, Hit& h) {
+    const int4 a = S.mat8[m8], b = S.mat8[m8 + 1];
+    return material_eval(S, a.x, a.y, a.z, a.w, b.x, u, v, h);
+}
+
+// aabb_model_hit / quad_model_hit on the aligned records (same arithmetic, same order; rec = first record << 8 | count)
+DEV float aabb_model_hit_rec(const SceneView& S, int rec, f3 no, f3 dir, f3 inv, Hit& h) {
+    const int boxes = rec & 0xFF, first = (int)((unsigned)rec >> 8);
+    float best = rt_inf();
+    bool hit = false;
+    for (int i = 0; i < boxes; i++) {
+        const int4 r0 = S.aabb_rec[(first + i) * 3], r1 = S.aabb_rec[(first + i) * 3 + 1], r2 = S.aabb_rec[(first + i) * 3 + 2];
+        Slabs s = slabs(as_float(r0.x), as_float(r0.y), as_float(r0.z), as_float(r0.w), as_float(r1.x), as_float(r1.y), no, inv);
+        float tn = slab_near(s), tf = slab_far(s);
+        if (tf < tn) continue;
+        if (tn != tn || tn >= best || tn < -kEps) continue;
+        Face f = face_map2(s, tn, no + dir * tn);
+        const int fl_all = r1.z;
+        int mat = r1.w, fl = 0;  // +z keeps the east material with flags 0 (see aabb_model_hit)
+        if (f.n.x == 1) { mat = r1.w; fl = fl_all >> 4; }
+        if (f.n.z == -1) { mat = r2.x; fl = fl_all >> 8; }
+        if (f.n.x == -1) { mat = r2.y; fl = fl_all >> 12; }
+        if (f.n.y == 1) { mat = r2.z; fl = fl_all >> 16; }
+        if (f.n.y == -1) { mat = r2.w; fl = fl_all >> 20; }
+        if (fl & 8) continue;
+        float u = f.u, v = f.v;
+        if (fl & 4) u = 1 - u;
+        if (fl & 2) v = 1 - v;
+        if (fl & 1) { float t = u; u = v; v = t; }
+        if (material_sample8(S, mat, u, v, h)) {
+            h.normal = f.n;
+            best = tn;
+            hit = true;
+        }
+    }
+    return hit ? best : rt_nan();
+}
+
+DEV float quad_model_hit_rec(const SceneView& S, int rec, f3 no, f3 dir, Hit& h) {
+    const int quads = rec & 0xFF, first = (int)((unsigned)rec >> 8);
+    float best = rt_inf();
+    bool hit = false;
+    for (int i = 0; i < quads; i++) {
+        const int4* __restrict__ q = S.quad_rec + (first + i) * 6;
+        const int4 r0 = q[0], r1 = q[1], r2 = q[2], r4 = q[4];
+        const f3 qo = mk3(as_float(r0.x), as_float(r0.y), as_float(r0.z));
+        const f3 xv = mk3(as_float(r1.x), as_float(r1.y), as_float(r1.z));
+        const f3 yv = mk3(as_float(r2.x), as_float(r2.y), as_float(r2.z));
+        const f3 n = mk3(as_float(r4.x), as_float(r4.y), as_float(r4.z));
+        const float n_qo = as_float(r0.w), xx = as_float(r1.w), yy = as_float(r2.w);
+        float denom = dot(dir, n);
+        if (!(denom < -kEps)) continue;
+        float t = -(dot(no, n) - n_qo) / denom;
+        if (!(t > -kEps && t < best)) continue;
+        f3 pt = (no + dir * t) - qo;
+        float u = dot(pt, xv) / xx;
+        float v = dot(pt, yv) / yy;
+        if (!(u >= 0 && u <= 1 && v >= 0 && v <= 1)) continue;
+        const int4 r3 = q[3], r5 = q[5];
+        float tu = as_float(r3.x) + (u * as_float(r3.y));
+        float tv = as_float(r3.z) + (v * as_float(r3.w));
+        if (material_eval(S, r5.x, r5.y, r5.z, r5.w, r4.w, tu, tv, h)) {
+            h.normal = n;
+            best = t;
+            hit = true;
+        }
+    }
+    return hit ? best : rt_nan();
+}
+
 // BlockPalette_intersectBlock — K/block.h:30-118.  bx/by/bz = integer cell of the march point.
 DEV float block_hit(const SceneView& S, int block, int bx, int by, int bz, f3 pos, f3 dir, f3 inv, Hit& h) {
     if (block == kAnyType) return rt_nan();
@@ -325,6 +403,7 @@ DEV float block_hit(const SceneView& S, int block, int bx, int by, int bz, f3 po
         type = a.x;
         ptr = a.y;
         if (type == 1) return cube_hit(S, a.z, a.w, b.x, b.y, b.z, no, pos, inv, h);
+        if (b.w != 0) return type == 2 ? aabb_model_hit_rec(S, b.w, no, dir, inv, h) : quad_model_hit_rec(S, b.w, no, dir, h);
     } else {
         type = S.blocks[block];
         ptr = S.blocks[block + 1];
