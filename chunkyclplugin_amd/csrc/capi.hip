@@ -76,6 +76,10 @@ struct chunky_scene {
     chunky_ctx* ctx = nullptr;
     DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, cube_info, quad_aux;
     DevBuf mat8, aabb_rec, quad_rec;                   // 16-byte-aligned re-layouts of the palettes (rt_device.hpp)
+    DevBuf bvh_rec, tri_rec;                           // both entity BVHs as 64-byte inner nodes, triangles as 80-byte records
+    std::vector<int32_t> host_trigs, host_world_bvh, host_actor_bvh;
+    int world_root = 0, actor_root = 0;                // first reference of each BVH in bvh_rec / tri_rec (rt_device.hpp)
+    bool bvh_dirty = false;
     std::vector<int32_t> host_blocks, host_materials, host_aabbs, host_quads;  // kept to rebuild what is derived from them
     bool derived_dirty = false;                        // block_info, cube_info, quad_aux, mat8, aabb_rec, quad_rec
     WideTree wide_meta;  // host copy kept so the kind bits can follow the block palette; nlev == 0 when absent
@@ -260,9 +264,11 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
         case CHUNKY_PALETTE_MATERIAL: scene->host_materials.assign(data, data + n); break;
         case CHUNKY_PALETTE_AABB: scene->host_aabbs.assign(data, data + n); break;
         case CHUNKY_PALETTE_QUAD: scene->host_quads.assign(data, data + n); break;
+        case CHUNKY_PALETTE_TRIG: scene->host_trigs.assign(data, data + n); break;
         default: break;
     }
     if (kind != CHUNKY_PALETTE_TRIG) scene->derived_dirty = true;  // rebuilt by scene_view before the next launch
+    if (kind == CHUNKY_PALETTE_TRIG || kind == CHUNKY_PALETTE_MATERIAL) scene->bvh_dirty = true;
     return CHUNKY_OK;
 }
 
@@ -300,6 +306,8 @@ extern "C" int chunky_scene_set_bvh(chunky_scene* scene, int which, const int32_
     (which == CHUNKY_BVH_WORLD ? scene->world_height : scene->actor_height) = height;
     DevBuf& dst = which == CHUNKY_BVH_WORLD ? scene->world_bvh : scene->actor_bvh;
     HIP_TRY(dst.upload(nodes, (size_t)n * 4, scene->ctx->stream));
+    (which == CHUNKY_BVH_WORLD ? scene->host_world_bvh : scene->host_actor_bvh).assign(nodes, nodes + n);
+    scene->bvh_dirty = true;
     if (which == CHUNKY_BVH_WORLD) {
         scene->world_empty = empty;
         scene->have_world = true;
@@ -535,6 +543,87 @@ static int rebuild_derived(chunky_scene* s) {
     return CHUNKY_OK;
 }
 
+// The two entity BVHs re-laid out for aligned 16-byte reads (rt_device.hpp has the layouts): every inner node becomes a
+// 64-byte record holding BOTH children (their references and boxes — what one visit of K/bvh.h:72-85 reads), every
+// triangle an 80-byte record with its material as a mat8 index.  A reference is the index of an inner record, or
+// -1 - (first triangle record << 6 | count) for a leaf.  The walk order, the tests and the arithmetic stay the reference's.
+// Returns false (no records: the packed arrays are walked as they are) when something does not fit: a leaf of more than
+// 63 triangles, a triangle pointer outside the palette, a material pointer that is not a whole material.
+static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_rec, std::vector<int32_t>* tri_rec, int* world_root,
+                              int* actor_root) {
+    const std::vector<int32_t>&T = s->host_trigs, &M = s->host_materials;
+    const size_t n_mats = M.size() / 6;
+    std::vector<int64_t> leaf_at(T.size(), -1);  // triangle pointer -> its leaf reference (leaves may be shared)
+    auto leaf_ref = [&](int64_t prim, int32_t* ref) {
+        if (prim < 0 || (size_t)prim >= T.size()) return false;
+        if (leaf_at[(size_t)prim] >= 0) {
+            *ref = (int32_t)(-1 - leaf_at[(size_t)prim]);
+            return true;
+        }
+        const int64_t count = T[(size_t)prim];
+        if (count < 0 || count > 63 || (size_t)(prim + 1 + 20 * count) > T.size()) return false;
+        const int64_t first = (int64_t)tri_rec->size() / 20;
+        if (first >= (1 << 24)) return false;
+        for (int64_t i = 0; i < count; i++) {
+            const int32_t* t = &T[(size_t)(prim + 1 + 20 * i)];
+            const int32_t mp = t[19];
+            if (mp < 0 || mp % 6 != 0 || (size_t)mp / 6 >= n_mats) return false;
+            const int32_t r[20] = {t[1], t[2], t[3], t[0],             // e1, flags
+                                   t[4], t[5], t[6], (mp / 6) * 2,     // e2, material (mat8 index)
+                                   t[7], t[8], t[9], t[13],            // o, t1.u
+                                   t[10], t[11], t[12], t[14],         // n, t1.v
+                                   t[15], t[16], t[17], t[18]};        // t2.u, t2.v, t3.u, t3.v
+            tri_rec->insert(tri_rec->end(), r, r + 20);
+        }
+        leaf_at[(size_t)prim] = (first << 6) | count;
+        *ref = (int32_t)(-1 - leaf_at[(size_t)prim]);
+        return true;
+    };
+    auto build = [&](const std::vector<int32_t>& N, bool empty, int* root) {
+        *root = 0;
+        if (empty || N.size() < 7) return true;
+        // reference of the node at int offset `at`: inner nodes get records in visiting (depth-first) order
+        struct Job { int64_t at; int32_t* slot; };
+        std::vector<std::pair<int64_t, int64_t>> todo;  // (node offset, index of the int in bvh_rec that receives its reference)
+        int32_t root_ref = 0;
+        // iterative: slot index -1 means the root reference
+        todo.emplace_back(0, -1);
+        int64_t guard = 0;
+        while (!todo.empty()) {
+            auto [at, slot] = todo.back();
+            todo.pop_back();
+            if (at < 0 || (size_t)at + 7 > N.size() || ++guard > (int64_t)N.size()) return false;
+            const int32_t head = N[(size_t)at];
+            int32_t ref;
+            if (head <= 0) {
+                if (!leaf_ref(-(int64_t)head, &ref)) return false;
+            } else {
+                const int64_t a = at + 7, b = head;
+                if ((size_t)a + 7 > N.size() || b < 0 || (size_t)b + 7 > N.size()) return false;
+                const int64_t idx = (int64_t)bvh_rec->size() / 16;
+                if (idx >= (1 << 30)) return false;
+                ref = (int32_t)idx;
+                bvh_rec->resize(bvh_rec->size() + 16, 0);
+                int32_t* r = &(*bvh_rec)[(size_t)idx * 16];
+                for (int w = 0; w < 6; w++) {
+                    r[4 + w] = N[(size_t)a + 1 + w];    // first child's box  (words 1, 2.xy)
+                    r[10 + w] = N[(size_t)b + 1 + w];   // second child's box (words 2.zw, 3)
+                }
+                todo.emplace_back(b, idx * 16 + 1);
+                todo.emplace_back(a, idx * 16 + 0);
+            }
+            if (slot < 0) root_ref = ref; else (*bvh_rec)[(size_t)slot] = ref;
+        }
+        *root = root_ref;
+        return true;
+    };
+    bvh_rec->clear();
+    tri_rec->clear();
+    if (!build(s->host_world_bvh, s->world_empty, world_root)) return false;
+    if (!build(s->host_actor_bvh, s->actor_empty, actor_root)) return false;
+    return true;
+}
+
 // Assemble the kernel-side view; Sun_new (K/sky.h:19-40) is evaluated here, on the host, with the
 // same rt_math.h the device uses.
 static int scene_view(chunky_scene* s, SceneView* v) {
@@ -591,6 +680,23 @@ static int scene_view(chunky_scene* s, SceneView* v) {
     }
     if (s->derived_dirty)
         if (int rc = rebuild_derived(s)) return rc;
+    if (s->bvh_dirty) {
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        s->bvh_rec.release();
+        s->tri_rec.release();
+        std::vector<int32_t> nodes, tris;
+        if ((!s->world_empty || !s->actor_empty) && build_bvh_records(s, &nodes, &tris, &s->world_root, &s->actor_root)) {
+            if (nodes.empty()) nodes.resize(16, 0);  // both roots are leaves
+            tris.resize(tris.size() + 20, 0);        // a step at the end of the last leaf reads one record past it
+            HIP_TRY(s->bvh_rec.upload(nodes.data(), nodes.size() * 4, s->ctx->stream));
+            HIP_TRY(s->tri_rec.upload(tris.data(), tris.size() * 4, s->ctx->stream));
+        }
+        s->bvh_dirty = false;
+    }
+    v->bvh_rec = (const int4*)s->bvh_rec.p;
+    v->tri_rec = (const int4*)s->tri_rec.p;
+    v->world_root = s->world_root;
+    v->actor_root = s->actor_root;
     v->quad_aux = (const float*)s->quad_aux.p;
     v->bvh_stack_entries = (s->world_height > s->actor_height ? s->world_height : s->actor_height) + 1;
     v->block_info = (const int4*)s->block_info.p;

@@ -323,6 +323,7 @@ struct LaneState {
     // render_pool: the top-level entry of the wide tree read last and its index (-1: none).  A third of the march steps
     // stay inside the top cell of the step before (8^3 blocks): those skip the first of the two dependent reads
     int top_idx, top_e;
+    int pid;  // render_pool with entity BVHs: which of the wave's to-visit stacks (LDS) belongs to this path
     // main record
     Hit h;
 };
@@ -1147,22 +1148,27 @@ struct PoolLds {
     int* list;    // [K] scratch: the slots taking part in a swap, by rank
 };
 
-DEV int phase_class(int st) { return st == ST_MARCH ? 0 : (st == ST_BLOCK ? 1 : (st == ST_DONE ? 3 : (st == ST_MODEL ? 4 : 2))); }
+DEV int phase_class(int st) {
+    return st == ST_MARCH ? 0 : (st == ST_BLOCK ? 1 : (st == ST_DONE ? 3 : (st == ST_MODEL ? 4 : ((st == ST_BVH || st == ST_LEAF) ? 5 : 2))));
+}
 
 DEV void pool_pack(const LaneState& L, uint4 (&v)[8]) {
-    const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.cand_level << 10);
+    const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.cand_level << 10) |
+                          ((unsigned)L.trace_hit << 14) | ((unsigned)L.bvh_which << 15) | ((unsigned)L.pid << 16);
     v[0] = make_uint4((unsigned)L.sidx, L.rng, misc, (unsigned)L.steps);
     v[1] = make_uint4(__float_as_uint(L.radiance.x), __float_as_uint(L.radiance.y), __float_as_uint(L.radiance.z), __float_as_uint(L.throughput.x));
     v[2] = make_uint4(__float_as_uint(L.throughput.y), __float_as_uint(L.throughput.z), __float_as_uint(L.o.x), __float_as_uint(L.o.y));
     v[3] = make_uint4(__float_as_uint(L.o.z), __float_as_uint(L.d.x), __float_as_uint(L.d.y), __float_as_uint(L.d.z));
     v[4] = make_uint4(__float_as_uint(L.inv.x), __float_as_uint(L.inv.y), __float_as_uint(L.inv.z), __float_as_uint(L.dist_march));
-    v[5] = make_uint4(0u, 0u, 0u, (unsigned)L.cand_data);
+    v[5] = make_uint4((unsigned)L.bvh_cur, (unsigned)L.bvh_top, __float_as_uint(L.bvh_dist), (unsigned)L.cand_data);  // dead words without entity BVHs
     v[6] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
     v[7] = make_uint4(__float_as_uint(L.h.color.x), __float_as_uint(L.h.color.y), __float_as_uint(L.h.color.z), __float_as_uint(L.h.emittance));
 }
 DEV void pool_unpack(LaneState& L, const uint4 (&v)[8]) {
     L.sidx = (int)v[0].x; L.rng = v[0].y; L.steps = (int)v[0].w;
     L.depth = v[0].z & 0xFFu; L.shadow = (v[0].z >> 8) & 1u; L.oct_hit = (v[0].z >> 9) & 1u; L.cand_level = (v[0].z >> 10) & 15u;
+    L.trace_hit = (v[0].z >> 14) & 1u; L.bvh_which = (v[0].z >> 15) & 1u; L.pid = (int)(v[0].z >> 16);
+    L.bvh_cur = (int)v[5].x; L.bvh_top = (int)v[5].y; L.bvh_dist = __uint_as_float(v[5].z);
     L.radiance = mk3(__uint_as_float(v[1].x), __uint_as_float(v[1].y), __uint_as_float(v[1].z));
     L.throughput = mk3(__uint_as_float(v[1].w), __uint_as_float(v[2].x), __uint_as_float(v[2].y));
     L.o = mk3(__uint_as_float(v[2].z), __uint_as_float(v[2].w), __uint_as_float(v[3].x));
@@ -1225,6 +1231,113 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
     return n;
 }
 
+// Entity BVHs in render_pool: Bvh_intersect (K/bvh.h:47-109) on the aligned records of rt_device.hpp, one node per
+// execution as in render_waves (inner visits and leaf visits are separate voted phases).  L.bvh_cur is a reference (inner
+// record index, or a leaf reference < 0), L.bvh_top the height of the path's to-visit stack; the stacks live in LDS, one
+// per PATH of the wave's pool (L.pid), so a path can be parked in the middle of a walk: entry e of stack p at
+// base[e * paths + p].
+struct PathStacks {
+    int* base;
+    int paths;  // 64 + K
+};
+// A walker is at a node: an inner record (bvh_cur >= 0) or a position inside a leaf (bvh_cur < 0:
+// -1 - (triangle record << 6 | triangles left)).  One STEP of the walk is one inner-node visit or ONE triangle test;
+// both start with the same four 16-byte reads (from one array or the other), so a step of the whole wave is a single
+// round trip to memory whatever its lanes are at.  Per path the sequence of box tests, triangle tests, pushes and pops
+// is K/bvh.h:47-109's.
+DEV int rbvh_enter(const SceneView& S, LaneState& L, int which) {
+    L.bvh_which = which;
+    L.bvh_cur = which ? S.actor_root : S.world_root;
+    L.bvh_top = 0;
+    return ST_BVH;
+}
+DEV int rbvh_begin(const SceneView& S, LaneState& L) {  // closestIntersect after the octree (K/kernel.h:16-18)
+    L.trace_hit = L.oct_hit;
+    if (L.shadow && L.trace_hit) return ST_SHADE;
+    L.bvh_dist = L.h.distance;
+    return rbvh_enter(S, L, S.world_bvh_empty ? 1 : 0);
+}
+DEV int rbvh_finished(const SceneView& S, LaneState& L) {
+    if (L.bvh_which == 0 && !S.actor_bvh_empty && !(L.shadow && L.trace_hit)) return rbvh_enter(S, L, 1);
+    return ST_SHADE;
+}
+DEV int rbvh_pop(const SceneView& S, LaneState& L, PathStacks K) {
+    if (L.bvh_top == 0) return rbvh_finished(S, L);
+    L.bvh_top -= 1;
+    L.bvh_cur = K.base[L.bvh_top * K.paths + L.pid];
+    return ST_BVH;
+}
+DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) {
+    const int cur = L.bvh_cur;
+    const bool inner = cur >= 0;
+    const int lref = -1 - cur, tri = lref >> 6, left = lref & 63;
+    const int4* __restrict__ p = inner ? S.bvh_rec + (size_t)(unsigned)cur * 4 : S.tri_rec + (size_t)(unsigned)tri * 5;
+    const int4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+    const float limit = L.shadow ? L.bvh_dist : L.h.distance;
+    if (inner) {
+        const int first = r0.x, second = r0.y;
+        const float t1 = box_quick(as_float(r1.x), as_float(r1.y), as_float(r1.z), as_float(r1.w), as_float(r2.x), as_float(r2.y), L.o, L.inv);
+        const float t2 = box_quick(as_float(r2.z), as_float(r2.w), as_float(r3.x), as_float(r3.y), as_float(r3.z), as_float(r3.w), L.o, L.inv);
+        const bool miss1 = (t1 != t1) || t1 > limit;
+        const bool miss2 = (t2 != t2) || t2 > limit;
+        if (miss1 & miss2) return rbvh_pop(S, L, K);
+        const bool go_first = !miss1 & (miss2 | (t1 < t2));  // K/bvh.h:86-103: the first child is the near one only when t1 < t2
+        if (!miss1 & !miss2) {
+            K.base[L.bvh_top * K.paths + L.pid] = go_first ? second : first;
+            L.bvh_top += 1;
+        }
+        L.bvh_cur = go_first ? first : second;
+        return ST_BVH;
+    }
+    if (left == 0) return rbvh_pop(S, L, K);  // an empty leaf
+    // Triangle_intersect (K/primitives.h:368-409) on the record {e1, flags} {e2, material} {o, t1.u} {n, t1.v} {t2.u, t2.v, t3.u, t3.v}
+    bool hit = false;
+    {
+        const int flags = r0.w;
+        const f3 e1 = mk3(as_float(r0.x), as_float(r0.y), as_float(r0.z));
+        const f3 e2 = mk3(as_float(r1.x), as_float(r1.y), as_float(r1.z));
+        const f3 to = mk3(as_float(r2.x), as_float(r2.y), as_float(r2.z));
+        const f3 pvec = cross(L.d, e2);
+        const float det = dot(e1, pvec);
+        const bool facing = ((flags >> 8) & 1) ? !(det > -kEps && det < kEps) : !(det > -kEps);
+        if (facing) {
+            const float recip = 1 / det;
+            const f3 tvec = L.o - to;
+            const float uu = dot(tvec, pvec) * recip;
+            if (!(uu < 0 || uu > 1)) {
+                const f3 qvec = cross(tvec, e1);
+                const float vv = dot(L.d, qvec) * recip;
+                if (!(vv < 0 || (uu + vv) > 1)) {
+                    const float tt = dot(e2, qvec) * recip;
+                    if (tt > kEps && tt < limit) {
+                        const int4 r4 = p[4];
+                        const float w = 1 - uu - vv;
+                        const float u = as_float(r2.w) * uu + as_float(r4.x) * vv + as_float(r4.z) * w;
+                        const float v = as_float(r3.w) * uu + as_float(r4.y) * vv + as_float(r4.w) * w;
+                        Hit t = L.h;
+                        if (material_sample8(S, r1.w, u, v, t)) {
+                            if (!L.shadow) {
+                                L.h.color = t.color;
+                                L.h.emittance = t.emittance;
+                                L.h.normal = mk3(as_float(r3.x), as_float(r3.y), as_float(r3.z));
+                                L.h.distance = tt;
+                            } else {
+                                L.bvh_dist = tt;
+                            }
+                            L.trace_hit = true;
+                            hit = true;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (L.shadow && hit) return rbvh_finished(S, L);  // a shadow ray only needs the boolean (K/rayTracer.cl:101-106)
+    if (left == 1) return rbvh_pop(S, L, K);
+    L.bvh_cur = -1 - (((tri + 1) << 6) | (left - 1));
+    return ST_BVH;
+}
+
 #ifndef CHUNKY_POOL_WAVES
 #define CHUNKY_POOL_WAVES 6  // waves per SIMD: the march is bound by the latency of its two dependent tree reads, every wave counts
 #endif
@@ -1252,21 +1365,43 @@ constexpr int kModelBatch = CHUNKY_MODEL_BATCH;  // model-block candidates that 
 constexpr int kPoolRefill = CHUNKY_POOL_REFILL;  // leave the march loop to refill once this many lanes are free and parked marchers exist
 constexpr int kSampleBatch = 256;                // sample indices a wave claims per atomic
 
-// stats (STATS = true), same layout as render_waves: [0..8] executions / lanes / cycles of MARCH, BLOCK, SHADE; [9..11] wave
-// lifetimes; [12] swap rounds, [13] paths swapped; [14..] parts of SHADE.
-template <int TREE, int K, bool STATS>
-__global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_pool(WaveArgs unused_by_name) {
-    constexpr int END = ST_SHADE;
+// stats (STATS = true), same layout as render_waves: [0..8] executions / lanes / cycles of MARCH, BLOCK (and the entity-BVH
+// walk), SHADE; [9..11] wave lifetimes; [12] swap rounds, [13] paths swapped; [14..] parts of SHADE.
+#ifndef CHUNKY_W_WALK
+#define CHUNKY_W_WALK 1
+#endif
+#ifndef CHUNKY_WALK_LEAVE
+#define CHUNKY_WALK_LEAVE 24
+#endif
+constexpr int kWalkLeave = CHUNKY_WALK_LEAVE;
+#ifndef CHUNKY_W_BVH
+#define CHUNKY_W_BVH 1
+#endif
+#ifndef CHUNKY_W_LEAF
+#define CHUNKY_W_LEAF 1
+#endif
+constexpr int kWWalk = CHUNKY_W_WALK, kWBvh = CHUNKY_W_BVH, kWLeaf = CHUNKY_W_LEAF;
+#ifndef CHUNKY_POOL_BVH_WAVES
+#define CHUNKY_POOL_BVH_WAVES 5
+#endif
+template <int TREE, int K, bool STATS, bool BVH = false>
+__global__ void __launch_bounds__(256, (STATS ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
+    constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     PoolLds P{nullptr, nullptr, nullptr};
-    if (K > 0) {
-        char* base = (char*)lds + wave * (K * 128 + K * 8);
+    PathStacks stacks{nullptr, 64 + K};
+    {
+        // per wave: K parked records, their tag / list scratch, then (BVH) one to-visit stack per path of the pool
+        const unsigned depth = BVH ? fresh_args()->stack_bytes : 0u;  // entries per stack
+        char* base = (char*)lds + wave * (K * 128 + K * 8 + (64 + K) * depth * 4);
         P.park = (uint4*)base;
         P.tags = (int*)(base + K * 128);
         P.list = P.tags + K;
+        stacks.base = (int*)(base + K * 128 + K * 8);
+        if (BVH && lane < K) P.park[lane] = make_uint4(0u, 0u, (unsigned)(64 + lane) << 16, 0u);  // the parked slots' stack ids
     }
-    LdsStack stack{lds, 0};  // no entity BVHs in this kernel
+    LdsStack stack{lds, 0};  // render_waves' per-lane stacks are not used here
     LaneState L;
     L.h.material = 0;
     L.h.normal = mk3(0, 0, 0);
@@ -1280,6 +1415,7 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
     L.sidx = 0;
     L.top_idx = -1;
     L.top_e = 0;
+    L.pid = lane;
     L.mean = mk3(0, 0, 0);
     L.slot = 0;
     L.serial = 0;
@@ -1306,20 +1442,31 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
     int ptag = lane < K ? ST_FRESH : ST_DONE;
     wave_lds_fence();
     for (;;) {
+        if (BVH && __ballot(st == ST_TRACED)) {  // octree part of some traces just ended: entity BVHs next
+            const SceneView S = arg_copy(&fresh_args()->S);
+            if (st == ST_TRACED) st = rbvh_begin(S, L);
+        }
         // the pool's census: paths waiting for each phase, in lanes and parked
         const int c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
         const int c_block = count_lanes(st == ST_BLOCK) + count_lanes(ptag == ST_BLOCK);
-        const int c_model = count_lanes(st == ST_MODEL) + count_lanes(ptag == ST_MODEL);
+        const int c_model = CHUNKY_POOL_SPLIT ? count_lanes(st == ST_MODEL) + count_lanes(ptag == ST_MODEL) : 0;
         const int c_shade = count_lanes(st == ST_SHADE || st == ST_FRESH) + count_lanes(ptag == ST_SHADE || ptag == ST_FRESH);
-        if ((c_march | c_block | c_model | c_shade) == 0) break;  // every lane and every slot is ST_DONE
+        const int c_bvh = BVH ? count_lanes(st == ST_BVH) + count_lanes(ptag == ST_BVH) : 0;
+        const int c_leaf = BVH ? count_lanes(st == ST_LEAF) + count_lanes(ptag == ST_LEAF) : 0;
+        if ((c_march | c_block | c_model | c_shade | c_bvh | c_leaf) == 0) break;  // every lane and every slot is ST_DONE
         // at most 64 paths run at once; among phases that can fill the wave SHADE and BLOCK go first (they feed the march).
         // Model blocks (slabs, plants: loops over boxes / quads, several dependent reads each) are rare and slow: they
         // wait until a fair number of them can share one execution, or nothing else is left.
         const int v_march = (c_march < 64 ? c_march : 64) * kWMarch, v_block = (c_block < 64 ? c_block : 64) * kWBlock,
                   v_shade = (c_shade < 64 ? c_shade : 64) * kWShade;
         int X = (v_shade >= v_block && v_shade >= v_march) ? 2 : (v_block >= v_march ? 1 : 0);
-        const int v_best = X == 2 ? v_shade : (X == 1 ? v_block : v_march);
+        int v_best = X == 2 ? v_shade : (X == 1 ? v_block : v_march);
         if (c_model >= kModelBatch || (c_model > 0 && v_best == 0)) X = 4;
+        if (BVH) {  // the walk through the entity BVHs (inner-node and leaf visits together) is one class of the pool
+            const int c_walk = c_bvh + c_leaf;
+            const int v_walk = (c_walk < 64 ? c_walk : 64) * kWWalk;
+            if (v_walk > v_best) { X = 5; v_best = v_walk; }
+        }
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         if (K > 0) {
@@ -1348,7 +1495,8 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
             // crowds — at worst every leaver joins it: nm < other + (n0 - nm) — or once enough lanes are free for a refill
             // from the parked marchers.  One bound, fixed on entry: the loop's bookkeeping is one popcount and one compare.
             const int other_b = c_block < 64 ? c_block : 64, other_s = c_shade < 64 ? c_shade : 64;
-            const int other = other_b > other_s ? other_b : other_s;
+            int other = other_b > other_s ? other_b : other_s;
+            // (with entity BVHs the walkers are not counted: they are the pool's standing crowd and wait in any case)
             int stay = (other + nm + 1) >> 1;
             if (K > 0 && parked_march >= kPoolRefill && stay < 65 - kPoolRefill) stay = 65 - kPoolRefill;
             if (stay < 1) stay = 1;
@@ -1384,12 +1532,42 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
             n_exec = count_lanes(st == ST_MODEL);
             const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_MODEL) st = block_phase<TREE, END, false, false>(S, L);
+        } else if (BVH && X == 5) {
+            // The walk: a path alternates between inner-node visits and leaf visits every few nodes, so the two are voted
+            // here, in a loop of their own (two counts per round) instead of through the pool's census.  The wave stays while
+            // the walkers outnumber what waits elsewhere, or until enough lanes are free for a refill from parked walkers.
+            const SceneView S = arg_copy(&fresh_args()->S);
+            int nw = count_lanes(st == ST_BVH);
+            n_exec = nw;
+            const int parked_walk = c_bvh + c_leaf - nw;
+            // The walk is nine tenths of the work in a scene with entities and everything else is cheap beside it: the other
+            // phases are served as soon as a small crowd waits for them (vote weight kWWalk against 4), so that the pool stays
+            // full of walkers; the wave leaves the walk when kWalkLeave lanes have finished theirs (they wait for SHADE now),
+            // or when that many are free and parked walkers can take their place.
+            int stay = nw - kWalkLeave + 1;
+            if (K > 0 && parked_walk > 0) {
+                const int refill = parked_walk < kWalkLeave ? parked_walk : kWalkLeave;
+                if (stay < 65 - refill) stay = 65 - refill;
+            }
+            if (stay < 1) stay = 1;
+            do {
+                if (STATS) {
+                    prof[3] += 1;
+                    prof[4] += (unsigned long long)nw;
+                }
+                if (st == ST_BVH) st = rwalk_step(S, L, stacks);
+                nw = count_lanes(st == ST_BVH);
+            } while (nw >= stay);
+            if (STATS) {
+                prof[3] -= 1;
+                prof[4] -= (unsigned long long)n_exec;
+            }
         } else {
             n_exec = count_lanes(st == ST_SHADE || st == ST_FRESH);
             WaveArgPtr A = fresh_args();
             const SceneView S = arg_copy(&A->S);
             const RenderOpts O = arg_copy(&A->O);
-            if (st == ST_SHADE) st = shade_phase<TREE, false, STATS>(S, O, L, stack, &parts);
+            if (st == ST_SHADE) st = shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
             part_begin<STATS>(&parts);
             if (st == ST_NEXT) {  // the path is finished: its radiance waits in the staging array for fold_kernel
                 // streamed past the caches (nt): written once, read once by fold_kernel; the L2 stays with the tree
@@ -1447,6 +1625,11 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : CHUNKY_POOL_WAVES)) render_p
                     prof[3 * k + 1] += (unsigned long long)n_exec;
                     prof[3 * k + 2] += dt;
                 }
+            if (X == 5) {  // the entity-BVH walk is profiled with BLOCK
+                prof[3] += 1;
+                prof[4] += (unsigned long long)n_exec;
+                prof[5] += dt;
+            }
             if (X == 4) {  // parts 8, 9: lanes served and cycles of the model phase
                 parts.t[8] += (unsigned long long)n_exec;
                 parts.t[9] += dt;
@@ -1712,6 +1895,9 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
         for (int i = 1; i < S.wide_nlev; i++)
             if (S.wide_bits[i] != 3) tree = -1;
     }
+    const bool bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
+    int depth = 0;  // entries per to-visit stack (the reference reserves 64, K/bvh.h:38; here: the height of the taller BVH + 1)
+    if (bvh) depth = S.bvh_stack_entries > 0 && S.bvh_stack_entries < kBvhStackEntries ? S.bvh_stack_entries : kBvhStackEntries;
     int park = kPoolPark;
     switch ((variant >> 6) & 3) {
         case 1: park = 0; break;
@@ -1722,7 +1908,20 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     if (const char* e = getenv("CHUNKY_DEBUG_POOL")) park = atoi(e);
     typedef void (*Kernel)(WaveArgs);
     Kernel k;
-    if (stats) {
+    if (bvh) {
+        // every path of the pool owns a to-visit stack in LDS: 32 parked paths when five workgroups per CU still fit, else 16
+        if (tree != 17 && tree != 18) tree = -1;
+        park = 5 * 4 * (32 * 136 + (64 + 32) * depth * 4) <= 160 * 1024 ? 32 : 16;
+        if (const char* e = getenv("CHUNKY_DEBUG_POOL")) park = atoi(e) >= 32 ? 32 : 16;
+        if (stats) {
+            park = 16;
+            k = tree == 17 ? render_pool<17, 16, true, true> : (tree == 18 ? render_pool<18, 16, true, true> : render_pool<-1, 16, true, true>);
+        } else if (park == 32) {
+            k = tree == 17 ? render_pool<17, 32, false, true> : (tree == 18 ? render_pool<18, 32, false, true> : render_pool<-1, 32, false, true>);
+        } else {
+            k = tree == 17 ? render_pool<17, 16, false, true> : (tree == 18 ? render_pool<18, 16, false, true> : render_pool<-1, 16, false, true>);
+        }
+    } else if (stats) {
         if (tree != 17) tree = -1;
         park = kPoolPark;
         k = tree == 17 ? render_pool<17, kPoolPark, true> : render_pool<-1, kPoolPark, true>;
@@ -1741,7 +1940,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
             default: tree = -1; k = render_pool<-1, kPoolPark, false>; break;
         }
     }
-    const size_t lds = (size_t)(block / 64) * (size_t)(park * 128 + park * 8);
+    const size_t lds = (size_t)(block / 64) * (size_t)(park * 128 + park * 8 + (64 + park) * depth * 4);
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
     if (e != hipSuccess) return e;
@@ -1751,10 +1950,10 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     const long long want = (n_samples + (long long)(block / 64) * (64 + park) - 1) / ((long long)(block / 64) * (64 + park));
     int grid = n_cu * bpc;
     if ((long long)grid > want) grid = (int)want;
-    if (chosen) *chosen = KernelChoice{tree, 1, 0, grid, park};
+    if (chosen) *chosen = KernelChoice{tree, 1, bvh ? 1 : 0, grid, park};
     e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
-    WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), 0u, staging, (unsigned)n_samples};
+    WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)depth, staging, (unsigned)n_samples};
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1768,7 +1967,8 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
                          float* staging) {
     const bool any_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
-    if (!(variant & 2) && !(variant & 8) && work_counter && staging && !any_bvh)
+    // render_pool: always without entity BVHs; with them when they could be re-laid out (rt_device.hpp bvh_rec / tri_rec)
+    if (!(variant & 2) && !(variant & 8) && work_counter && staging && (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1))))
         return launch_pool(variant, S, C, O, T, P, res, work_counter, stream, chosen, staging);
     if (!(variant & 2) && work_counter) {
         const bool stats = (variant & 4) != 0;  // work_counter[2..] = 9 x u64 phase profile

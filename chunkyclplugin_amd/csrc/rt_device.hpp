@@ -89,6 +89,14 @@ struct SceneView {
     const int4* __restrict__ mat8;
     const int4* __restrict__ aabb_rec;
     const int4* __restrict__ quad_rec;
+    // Both entity BVHs re-laid out (capi.hip build_bvh_records), null when they could not be:
+    //   bvh_rec  per inner node four words {ref A, ref B, 0, 0} {A: xmin, xmax, ymin, ymax} {A: zmin, zmax, B: xmin, xmax}
+    //            {B: ymin, ymax, zmin, zmax} — A is the child that follows the node (K/bvh.h:73), B the one it points at
+    //   tri_rec  per triangle five words {e1, flags} {e2, material (mat8 index)} {o, t1.u} {n, t1.v} {t2.u, t2.v, t3.u, t3.v}
+    // A reference is an inner record's index, or -1 - (first triangle record << 6 | count) for a leaf.
+    const int4* __restrict__ bvh_rec;
+    const int4* __restrict__ tri_rec;
+    int world_root, actor_root;  // reference of each BVH's root
 };
 
 struct CameraView {

@@ -143,17 +143,22 @@ def entity_world(outdoor):
     return scenes.add_entities(outdoor, 100000, seed=11, actor_tris=5000, region=((40, 90, 40), (470, 170, 470)))
 
 
-@pytest.mark.parametrize("world,passes,group", [(1, 16, 8), (4, 32, 16)])
-def test_entity_kernels(gpu_instance, port, entity_world, world, passes, group):
-    """render_waves<17, false, 8 | 16, true> on the 100 k-triangle world: BVHs of height ~17, both BVHs walked."""
+@pytest.mark.parametrize("world,passes,group,variant", [(1, 16, 0, 0), (4, 32, 0, 0), (1, 16, 8, 8), (4, 32, 16, 8)])
+def test_entity_kernels(gpu_instance, port, entity_world, world, passes, group, variant):
+    """The 100 k-triangle world (BVHs of height ~17, both BVHs walked): render_pool<17, 16 | 32, bvh> on the aligned
+    node / triangle records (default), and render_waves<17, false, 8 | 16, true> on the packed arrays (variant 8)."""
     sc = entity_world
     seeds = native.java_random_ints(passes)
     loader, r = make(gpu_instance, sc)
+    r.set_option(native.OPT_KERNEL, variant)
     rank = world - 1
     r.set_shard(rank, world, 256)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["group"], info["bvh"]) == (17, group, True), info
+    if variant == 0:
+        assert (info["tree"], info["bvh"]) == (17, True) and info["pool"] in (16, 32), info
+    else:
+        assert (info["tree"], info["group"], info["bvh"], info["pool"]) == (17, group, True, -1), info
     own = parallel.owned_gids(sc.width * sc.height, rank, world, 256)
     mine = np.intersect1d(row_gids(sc, (101, 411, 540, 799, 1003)), own)
     compare_rows(r, port, sc, seeds, mine, f"entities share 1/{world}")
