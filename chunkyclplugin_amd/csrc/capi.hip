@@ -122,7 +122,7 @@ struct chunky_render {
     }
 };
 
-constexpr size_t kStagingBytes = (size_t)4 << 30;  // 4 GiB: 1920x1080 x 128 passes is 3.2 GB
+constexpr size_t kStagingBytes = (size_t)8 << 30;  // 8 GiB: 1920x1080 x 256 passes is 6.4 GB (of 288)
 
 static int n_local_slots(int n_pixels, const ShardView& t) {
     if (t.world == 1) return n_pixels;

@@ -451,13 +451,18 @@ def value_noise2(rng: np.random.Generator, n: int, octaves: int = 4, base: int =
 def outdoor_world(chunks: int = 32, height: int = 256, seed: int = 20260101,
                   width: int = 1920, img_height: int = 1080, sun_flag: bool = True,
                   aabb_frac: float = 0.02, quad_frac: float = 0.01, trees: bool = True,
-                  emitters: float = 0.0, octree_order: str = "bfs") -> PackedScene:
+                  emitters: float = 0.0, octree_order: str = "bfs", atlas_tiles: Tuple[int, int] = (8, 8),
+                  water: bool = False) -> PackedScene:
     """BASELINE.json config 3: chunks x chunks Minecraft chunks (16 columns each), `height` tall,
     seeded value-noise terrain with bedrock/stone/dirt/grass layers, ANY_TYPE hidden interior,
     ~`aabb_frac` slab (AABB-model) and ~`quad_frac` plant (quad-model) blocks on the surface,
     optional trees with alpha-cut-out leaf cubes, 12 procedural 16x16 textures, 128^2 baked sky,
     sun altitude 0.6 / azimuth 1.2 / intensity 1.25.  With chunks=32, height=256 the world is
-    512x256x512 blocks inside a depth-9 octree."""
+    512x256x512 blocks inside a depth-9 octree.
+
+    `atlas_tiles` bounds the atlas layers (in 16-px tiles): (2, 2) pushes the thirteen textures over four layers, with
+    tiles at y = 1 whose location bit 13 runs into the kernel's 19-bit layer mask (K/textureAtlas.h:13, quirk B#7).
+    `water` floods the low ground with a cube whose material carries the biome-water tint (type 3, K/material.h:61-72)."""
     rng = np.random.default_rng(seed)
     n = chunks * 16
     S = max(n, height)
@@ -465,7 +470,7 @@ def outdoor_world(chunks: int = 32, height: int = 256, seed: int = 20260101,
     S = 1 << depth
 
     # --- textures + materials -------------------------------------------------------------
-    ab = AtlasBuilder(8, 8)
+    ab = AtlasBuilder(*atlas_tiles)
     tex = {
         "bedrock": ab.add(noise_texture(rng, (60, 60, 60), 30)),
         "stone": ab.add(noise_texture(rng, (125, 125, 125), 14)),
@@ -480,14 +485,18 @@ def outdoor_world(chunks: int = 32, height: int = 256, seed: int = 20260101,
         "snow": ab.add(noise_texture(rng, (240, 245, 250), 6)),
         "sun": ab.add(noise_texture(rng, (255, 250, 230), 4, size=32)),
     }
+    if water:
+        tex["water"] = ab.add(noise_texture(rng, (200, 200, 200), 12))
     atlas, recs = ab.build()
     pal = Palettes()
-    m = {k: pal.material(texture=recs[v]) for k, v in tex.items() if k not in ("grass", "leaves", "plant", "glow", "sun")}
+    m = {k: pal.material(texture=recs[v]) for k, v in tex.items() if k not in ("grass", "leaves", "plant", "glow", "sun", "water")}
     m["grass"] = pal.material(texture=recs[tex["grass"]], tint=2 << 24)
     m["leaves"] = pal.material(texture=recs[tex["leaves"]], tint=1 << 24)
     m["plant"] = pal.material(texture=recs[tex["plant"]], tint=0xFF000000 | 0x6FB040)
     m["glow"] = pal.material(texture=recs[tex["glow"]], emittance=1.0 if emitters > 0 else 0.0)
     m["flat"] = pal.material(argb=0xFF3060C0)
+    if water:
+        m["water"] = pal.material(texture=recs[tex["water"]], tint=3 << 24)
 
     B = {"air": pal.block_invisible()}
     for k in ("bedrock", "stone", "dirt", "grass", "sand", "log", "leaves", "plank", "glow", "snow", "flat"):
@@ -509,6 +518,8 @@ def outdoor_world(chunks: int = 32, height: int = 256, seed: int = 20260101,
         quad((0.85, 0, 0.85), (-0.7, 0, -0.7), (0, 1, 0)),
         quad((0.15, 0, 0.85), (0.7, 0, -0.7), (0, 1, 0)),
         quad((0.85, 0, 0.15), (-0.7, 0, 0.7), (0, 1, 0))])
+    if water:
+        B["water"] = pal.block_cube(m["water"])
     nblocks = len(pal.blocks) // 2
     opaque = np.zeros(nblocks, bool)
     for k in ("bedrock", "stone", "dirt", "grass", "sand", "log", "plank", "glow", "snow", "flat"):
@@ -533,6 +544,9 @@ def outdoor_world(chunks: int = 32, height: int = 256, seed: int = 20260101,
     t[(ys <= H3) & (ys > H3 - 3) & inside & beach] = B["sand"]
     t[(ys == H3) & inside & peak] = B["snow"]
     t[(ys == 0) & inside] = B["bedrock"]
+    if water:  # a water table a little above the beach line: every column below it is filled up to it
+        level = int(lo_h + 0.2 * (hi_h - lo_h))
+        t[(ys > H3) & (ys <= level) & inside] = B["water"]
 
     # surface decorations
     r = rng.random((n, n))

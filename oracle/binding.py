@@ -216,6 +216,33 @@ class PortLib(_Lib):
                                   _ptr(res), threads)
         return res
 
+    def geom(self, which: int, a, b=None) -> np.ndarray:
+        """dot (0) / cross (1) / normalize (2) / general fmod (3) on rows of 3 floats, as rt_math.h defines them."""
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(a if b is None else b, np.float32).reshape(-1, 3)
+        out = np.zeros_like(a)
+        self.lib.port_geom.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.port_geom.restype = None
+        self.lib.port_geom(which, len(a), _ptr(a), _ptr(b), _ptr(out))
+        return out
+
+    def mirror_linear(self, s, w: int):
+        s = np.ascontiguousarray(s, np.float32)
+        i0, i1, a = np.zeros(s.size, np.int32), np.zeros(s.size, np.int32), np.zeros(s.size, np.float32)
+        self.lib.port_mirror_linear.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.port_mirror_linear.restype = None
+        self.lib.port_mirror_linear(s.size, _ptr(s), int(w), _ptr(i0), _ptr(i1), _ptr(a))
+        return i0, i1, a
+
+    def sample_linear(self, st, rgba) -> np.ndarray:
+        st = np.ascontiguousarray(st, np.float32).reshape(-1, 2)
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        out = np.zeros((len(st), 4), np.float32)
+        self.lib.port_sample_linear.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.lib.port_sample_linear.restype = None
+        self.lib.port_sample_linear(len(st), _ptr(st), _ptr(rgba), rgba.shape[1], rgba.shape[0], _ptr(out))
+        return out
+
     def counters(self, enable: Optional[bool] = None, reset: bool = False) -> dict:
         if enable is not None:
             self.lib.port_counters_enable(1 if enable else 0)

@@ -807,6 +807,54 @@ void port_math(int which, int n, const float* a, const float* b, float* out) {
     }
 }
 
+/* The geometric builtins and the sky sampler as this restatement evaluates them (rt_math.h), for tests/test_rt_math.py:
+ * which 0 dot -> out[0]; 1 cross -> out[0..2]; 2 normalize(a) -> out[0..2]; 3 fmod(a[0], b[0]) for ANY b (the kernel only
+ * uses b = 1; the OpenCL shim of oracle/_ref falls back to C fmodf otherwise) -> out[0]. */
+void port_geom(int which, int n, const float* a3, const float* b3, float* out3) {
+    for (int i = 0; i < n; i++) {
+        const float* a = a3 + 3 * i;
+        const float* b = b3 + 3 * i;
+        float* o = out3 + 3 * i;
+        o[0] = o[1] = o[2] = 0;
+        if (which == 0) {
+            o[0] = rt_dot3(a[0], a[1], a[2], b[0], b[1], b[2]);
+        } else if (which == 1) {
+            v3 c = cross3(V3(a[0], a[1], a[2]), V3(b[0], b[1], b[2]));
+            o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        } else if (which == 2) {
+            v3 c = normalize3(V3(a[0], a[1], a[2]));
+            o[0] = c.x; o[1] = c.y; o[2] = c.z;
+        } else if (which == 3) {
+            o[0] = b[0] == 1.0f ? rt_fmod1(a[0]) : fmodf(a[0], b[0]);
+        }
+    }
+}
+/* CLK_NORMALIZED_COORDS_TRUE | CLK_ADDRESS_MIRRORED_REPEAT | CLK_FILTER_LINEAR on an RGBA8 image (K/sky.h:95-105): the
+ * indices / weight of rt_mirror_linear along one axis, and the filtered texel at (s, t). */
+void port_mirror_linear(int n, const float* s, int w, int32_t* i0, int32_t* i1, float* a) {
+    for (int i = 0; i < n; i++) {
+        int j0, j1;
+        rt_mirror_linear(s[i], w, &j0, &j1, &a[i]);
+        i0[i] = j0;
+        i1[i] = j1;
+    }
+}
+void port_sample_linear(int n, const float* st, const uint8_t* rgba, int w, int h, float* out4) {
+    for (int i = 0; i < n; i++) {
+        int i0, i1, j0, j1;
+        float a, b;
+        rt_mirror_linear(st[2 * i], w, &i0, &i1, &a);
+        rt_mirror_linear(st[2 * i + 1], h, &j0, &j1, &b);
+        const uint8_t* t00 = rgba + 4 * ((size_t)j0 * w + i0);
+        const uint8_t* t10 = rgba + 4 * ((size_t)j0 * w + i1);
+        const uint8_t* t01 = rgba + 4 * ((size_t)j1 * w + i0);
+        const uint8_t* t11 = rgba + 4 * ((size_t)j1 * w + i1);
+        float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+        for (int k = 0; k < 4; k++)
+            out4[4 * i + k] = w00 * rt_unorm8(t00[k]) + w10 * rt_unorm8(t10[k]) + w01 * rt_unorm8(t01[k]) + w11 * rt_unorm8(t11[k]);
+    }
+}
+
 /* ------------------------------------------------------------------------------ tone map ----
  * `filter`, tonemap/include/post_processing_filter.cl:5-51, with fp64 present (double.h:19-21):
  * per channel c = (float)input * exposure, then the curve selected by `type`, then color_to_argb

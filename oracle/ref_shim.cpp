@@ -47,14 +47,23 @@ size_t ocl_get_global_id(unsigned) { return tls_gid; }
 void* ocl_translate_sampler(int init) OCL("__translate_sampler_initializer");
 void* ocl_translate_sampler(int init) { return (void*)(intptr_t)init; }
 
+/* REF_SHIM_LIBM (make ref_libm): the same reference object linked against ANOTHER conforming platform — glibc's
+ * correctly-rounded-ish transcendentals, unfused dot / cross / normalize — for the tolerance study of
+ * tools/tolerance_study.py: how far two conforming OpenCL platforms drift apart on whole images (north_star: 1e-5). */
+#ifdef REF_SHIM_LIBM
+#include <math.h>
+#define ALT(native, ours) (native)
+#else
+#define ALT(native, ours) (ours)
+#endif
 float ocl_cos(float x) OCL("_Z3cosf");
-float ocl_cos(float x) { return rt_cos(x); }
+float ocl_cos(float x) { return ALT(cosf(x), rt_cos(x)); }
 float ocl_sin(float x) OCL("_Z3sinf");
-float ocl_sin(float x) { return rt_sin(x); }
+float ocl_sin(float x) { return ALT(sinf(x), rt_sin(x)); }
 float ocl_acos(float x) OCL("_Z4acosf");
-float ocl_acos(float x) { return rt_acos(x); }
+float ocl_acos(float x) { return ALT(acosf(x), rt_acos(x)); }
 float ocl_asin(float x) OCL("_Z4asinf");
-float ocl_asin(float x) { return rt_asin(x); }
+float ocl_asin(float x) { return ALT(asinf(x), rt_asin(x)); }
 float ocl_fabs(float x) OCL("_Z4fabsf");
 float ocl_fabs(float x) { return rt_fabs(x); }
 float ocl_sqrt(float x) OCL("_Z4sqrtf");
@@ -64,7 +73,7 @@ cl_float4 ocl_sqrt4(cl_float4 v) {
     return (cl_float4){rt_sqrt(v.x), rt_sqrt(v.y), rt_sqrt(v.z), rt_sqrt(v.w)};
 }
 float ocl_atan2(float y, float x) OCL("_Z5atan2ff");
-float ocl_atan2(float y, float x) { return rt_atan2(y, x); }
+float ocl_atan2(float y, float x) { return ALT(atan2f(y, x), rt_atan2(y, x)); }
 float ocl_fmod(float x, float y) OCL("_Z4fmodff");
 float ocl_fmod(float x, float y) {
     /* the reference only ever calls fmod(., 1) (sky.h:102) */
@@ -94,16 +103,25 @@ cl_float3 ocl_clamp3(cl_float3 v, float lo, float hi) {
 int ocl_isnan(float x) OCL("_Z5isnanf");
 int ocl_isnan(float x) { return rt_isnan(x); }
 float ocl_dot(cl_float3 a, cl_float3 b) OCL("_Z3dotDv3_fS_");
-float ocl_dot(cl_float3 a, cl_float3 b) { return rt_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
+float ocl_dot(cl_float3 a, cl_float3 b) { return ALT(a.x * b.x + a.y * b.y + a.z * b.z, rt_dot3(a.x, a.y, a.z, b.x, b.y, b.z)); }
 cl_float3 ocl_cross(cl_float3 a, cl_float3 b) OCL("_Z5crossDv3_fS_");
 cl_float3 ocl_cross(cl_float3 a, cl_float3 b) {
+#ifdef REF_SHIM_LIBM
+    return (cl_float3){a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+#else
     return (cl_float3){rt_cross_c(a.y, b.z, a.z, b.y), rt_cross_c(a.z, b.x, a.x, b.z),
                        rt_cross_c(a.x, b.y, a.y, b.x)};
+#endif
 }
 cl_float3 ocl_normalize(cl_float3 v) OCL("_Z9normalizeDv3_f");
 cl_float3 ocl_normalize(cl_float3 v) {
+#ifdef REF_SHIM_LIBM
+    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return (cl_float3){v.x / len, v.y / len, v.z / len};
+#else
     float r = rt_rlen3(v.x, v.y, v.z);
     return (cl_float3){v.x * r, v.y * r, v.z * r};
+#endif
 }
 cl_float3 ocl_floor3(cl_float3 v) OCL("_Z5floorDv3_f");
 cl_float3 ocl_floor3(cl_float3 v) { return (cl_float3){rt_floor(v.x), rt_floor(v.y), rt_floor(v.z)}; }

@@ -41,6 +41,12 @@ def make(name: str) -> scenes.PackedScene:
     if name == "inside":
         sc = _outdoor()
         return dataclasses.replace(sc, camera=scenes.look_at_camera((10.3, 9.2, 12.1), (20, 14, 20), 90.0))
+    if name == "atlas_layers":   # thirteen textures over four 32x32 atlas layers (quirk B#7: the 19-bit layer mask)
+        return scenes.outdoor_world(chunks=2, height=48, seed=101, width=W, img_height=H, aabb_frac=0.08, quad_frac=0.05,
+                                    emitters=0.02, atlas_tiles=(2, 2))
+    if name == "water":          # tint type 3 (biome water, K/material.h:61-72) beside types 1, 2 and 0xFF
+        return scenes.outdoor_world(chunks=2, height=48, seed=101, width=W, img_height=H, aabb_frac=0.08, quad_frac=0.05,
+                                    emitters=0.02, water=True)
     if name == "indoor":
         return scenes.indoor_room(size=24, seed=7, width=W, img_height=H, emitter_frac=0.03)
     if name == "indoor_sun":
@@ -49,7 +55,7 @@ def make(name: str) -> scenes.PackedScene:
     raise KeyError(name)
 
 
-NAMES = ["outdoor", "outdoor_nosun", "entities", "dof", "pregen", "inside", "indoor", "indoor_sun"]
+NAMES = ["outdoor", "outdoor_nosun", "entities", "dof", "pregen", "inside", "indoor", "indoor_sun", "atlas_layers", "water"]
 RECORD_GIDS = np.arange(0, W * H, 37, dtype=np.int32)
 
 

@@ -124,6 +124,21 @@ def test_city_kernel(gpu_instance, port):
     loader.close()
 
 
+def test_config0_plumbing_image(gpu_instance, port):
+    """BASELINE configs[0] — benchmark/OpenCL_test at 256x256, 16 spp (recorded on the CPU path by tools/config0_cpu.py,
+    profiles/r02_config0_cpu.json): the whole image from the HIP path equals the CPU path's, bit for bit."""
+    from chunkyclplugin_amd import octree2
+    sc = octree2.cached_benchmark_scene(256, 256)
+    seeds = native.java_random_ints(16)
+    loader, r = make(gpu_instance, sc)
+    r.render_passes(seeds)
+    got = r.read()
+    want = port.render_passes(sc, seeds, threads=THREADS)
+    np.testing.assert_array_equal(bits(got), bits(want))
+    r.close()
+    loader.close()
+
+
 def test_indoor_kernel(gpu_instance, port):
     """BASELINE configs[3]: the emitter-lit room of tools/config_bench.py (sun flag 0), 1920x1080, 32 passes."""
     sc = scenes.indoor_room(size=64, width=1920, img_height=1080)
