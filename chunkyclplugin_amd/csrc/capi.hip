@@ -77,6 +77,9 @@ struct chunky_scene {
     DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, cube_info, quad_aux;
     DevBuf mat8, aabb_rec, quad_rec;                   // 16-byte-aligned re-layouts of the palettes (rt_device.hpp)
     DevBuf bvh_rec, tri_rec;                           // both entity BVHs as 64-byte inner nodes, triangles as 80-byte records
+    DevBuf emitters;                                   // emitter next-event estimation: {x, y, z, level << 25 | block} per emitter leaf
+    std::vector<int32_t> host_octree, host_emitters;
+    bool emitters_dirty = true;
     std::vector<int32_t> host_trigs, host_world_bvh, host_actor_bvh;
     int world_root = 0, actor_root = 0;                // first reference of each BVH in bvh_rec / tri_rec (rt_device.hpp)
     bool bvh_dirty = false;
@@ -102,7 +105,7 @@ struct chunky_render {
     CameraView cam{};
     bool have_camera = false;
     DevBuf rays;
-    RenderOpts opts{256, 5, 13.0f};
+    RenderOpts opts{256, 5, 13.0f, -1, 1, 0, 0};
     int kernel_variant = 0;
     ShardView shard{0, 1, 256, 0};
     DevBuf own_fb, work_counter;
@@ -112,7 +115,7 @@ struct chunky_render {
     std::vector<hipEvent_t> free_events;
     float timed_ms = 0;
     int timed_launches = 0;
-    KernelChoice last_choice{0, 0, 0, 0, -1};  // what the most recent launch ran (chunky_render_kernel_info)
+    KernelChoice last_choice{0, 0, 0, 0, -1, 0};  // what the most recent launch ran (chunky_render_kernel_info)
     ~chunky_render() {
         for (auto& p : pending) {
             (void)hipEventDestroy(p.first);
@@ -220,6 +223,8 @@ extern "C" int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree,
     }
     HIP_TRY(scene->octree.upload(tree, (size_t)n * 4, scene->ctx->stream));
     scene->octree_depth = depth;
+    scene->host_octree.assign(tree, tree + n);
+    scene->emitters_dirty = true;
     // wide re-layout for the fast lookup; scenes it cannot express keep the reference layout only
     scene->wide.release();
     scene->wide_meta = WideTree();
@@ -268,6 +273,7 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
         default: break;
     }
     if (kind != CHUNKY_PALETTE_TRIG) scene->derived_dirty = true;  // rebuilt by scene_view before the next launch
+    if (kind == CHUNKY_PALETTE_BLOCK || kind == CHUNKY_PALETTE_MATERIAL) scene->emitters_dirty = true;
     if (kind == CHUNKY_PALETTE_TRIG || kind == CHUNKY_PALETTE_MATERIAL) scene->bvh_dirty = true;
     return CHUNKY_OK;
 }
@@ -364,6 +370,23 @@ extern "C" int chunky_scene_set_sky(chunky_scene* scene, const uint8_t* rgba, in
     return CHUNKY_OK;
 }
 
+static void list_emitters(const chunky_scene* s, std::vector<int32_t>* out);
+extern "C" int chunky_scene_emitters(chunky_scene* scene, int32_t* out4, int32_t cap, int32_t* count) {
+    LOCK_SCENE(scene);
+    if (!count || cap < 0 || (cap > 0 && !out4)) return fail(CHUNKY_E_INVALID, "scene_emitters: bad arguments");
+    if (scene->emitters_dirty) {
+        list_emitters(scene, &scene->host_emitters);
+        HIP_TRY(hipStreamSynchronize(scene->ctx->stream));
+        scene->emitters.release();
+        if (!scene->host_emitters.empty()) HIP_TRY(scene->emitters.upload(scene->host_emitters.data(), scene->host_emitters.size() * 4, scene->ctx->stream));
+        scene->emitters_dirty = false;
+    }
+    const int32_t n = (int32_t)(scene->host_emitters.size() / 4);
+    *count = n;
+    memcpy(out4, scene->host_emitters.data(), (size_t)(n < cap ? n : cap) * 16);
+    return CHUNKY_OK;
+}
+
 extern "C" int chunky_scene_set_sun(chunky_scene* scene, const int32_t sun[6]) {
     LOCK_SCENE(scene);
     if (!sun) return fail(CHUNKY_E_INVALID, "set_sun: NULL");
@@ -442,7 +465,7 @@ static int rebuild_derived(chunky_scene* s) {
     const size_t n_blocks = B.size() / 2, n_mats = M.size() / 6;
     std::vector<int32_t> mat8(n_mats * 8, 0);
     for (size_t m = 0; m < n_mats; m++)
-        for (int w = 0; w < 5; w++) mat8[m * 8 + w] = M[m * 6 + w];
+        for (int w = 0; w < 6; w++) mat8[m * 8 + w] = M[m * 6 + w];  // word 5 (spec | metal | rough) rides in the second word
     auto mat_index = [&](int32_t ptr, int32_t* out) {  // packed material pointer -> index of its first 16-byte word in mat8
         if (ptr < 0 || ptr % 6 != 0 || (size_t)ptr / 6 >= n_mats) return false;
         *out = (ptr / 6) * 2;
@@ -459,6 +482,7 @@ static int rebuild_derived(chunky_scene* s) {
         if (type == 1) {
             if (ptr >= 0 && (size_t)ptr + 5 <= M.size()) {
                 for (int w = 0; w < 5; w++) e[2 + w] = M[(size_t)ptr + w];
+                if ((size_t)ptr + 6 <= M.size()) e[7] = M[(size_t)ptr + 5];  // material word 5 (extensions)
                 if (!(e[2] & 2)) {  // no emittance texture: the 16-byte form carries everything
                     uint32_t* c = &cube[k * 4];
                     c[0] = 0x80000000u | (((uint32_t)e[6] & 0xFFu) << 8) | ((uint32_t)e[2] & 7u);
@@ -517,9 +541,10 @@ static int rebuild_derived(chunky_scene* s) {
                     r[16] = a[0]; r[17] = a[1]; r[18] = a[2];                // unit normal
                     int32_t m8 = 0;
                     ok = mat_index(q[13], &m8);                              // the quad's material, inline: one dependent read less
+                    if (ok && (M[(size_t)q[13]] & 2)) ok = false;          // an emittance texture needs the full word: packed path
                     if (ok) {
                         const int32_t* m = &M[(size_t)q[13]];
-                        r[19] = m[4];
+                        r[19] = (m[4] & 0xFF) | (int32_t)((uint32_t)m[5] << 8);
                         r[20] = m[0]; r[21] = m[1]; r[22] = m[2]; r[23] = m[3];
                     }
                 }
@@ -624,6 +649,36 @@ static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_r
     return true;
 }
 
+// The emitter list of the next-event-estimation extension (same rule and order as oracle/port.c
+// port_list_emitters): every octree leaf whose block is a full cube with a non-zero emittance byte and no emittance
+// texture, in pre-order (children in index order), as {x, y, z, level << 25 | block pointer}.
+static void list_emitters(const chunky_scene* s, std::vector<int32_t>* out) {
+    out->clear();
+    const std::vector<int32_t>&T = s->host_octree, &B = s->host_blocks, &M = s->host_materials;
+    if (T.empty() || s->octree_depth < 0 || s->octree_depth > 15) return;
+    struct Item { int64_t node; int x, y, z, level; };
+    std::vector<Item> todo{{0, 0, 0, 0, s->octree_depth}};
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        const int32_t v = T[(size_t)it.node];
+        if (v > 0) {
+            const int h = 1 << (it.level - 1);
+            for (int c = 7; c >= 0; c--)  // pushed in reverse: popped in index order
+                todo.push_back({(int64_t)v + c, it.x + ((c >> 2) & 1) * h, it.y + ((c >> 1) & 1) * h, it.z + (c & 1) * h, it.level - 1});
+            continue;
+        }
+        const int64_t block = -(int64_t)v;
+        if (block == 0 || block == 0x7FFFFFFE || block + 1 >= (int64_t)B.size() || block >= (1 << 25)) continue;
+        if (B[(size_t)block] != 1) continue;
+        const int64_t mp = B[(size_t)block + 1];
+        if (mp < 0 || (size_t)mp + 6 > M.size()) continue;
+        if ((M[(size_t)mp] & 2) || (M[(size_t)mp + 4] & 0xFF) == 0) continue;
+        const int32_t rec[4] = {it.x, it.y, it.z, (int32_t)((it.level << 25) | (int32_t)block)};
+        out->insert(out->end(), rec, rec + 4);
+    }
+}
+
 // Assemble the kernel-side view; Sun_new (K/sky.h:19-40) is evaluated here, on the host, with the
 // same rt_math.h the device uses.
 static int scene_view(chunky_scene* s, SceneView* v) {
@@ -693,6 +748,15 @@ static int scene_view(chunky_scene* s, SceneView* v) {
         }
         s->bvh_dirty = false;
     }
+    if (s->emitters_dirty) {
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        list_emitters(s, &s->host_emitters);
+        s->emitters.release();
+        if (!s->host_emitters.empty()) HIP_TRY(s->emitters.upload(s->host_emitters.data(), s->host_emitters.size() * 4, s->ctx->stream));
+        s->emitters_dirty = false;
+    }
+    v->emitters = (const int4*)s->emitters.p;
+    v->n_emitters = (int)(s->host_emitters.size() / 4);
     v->bvh_rec = (const int4*)s->bvh_rec.p;
     v->tri_rec = (const int4*)s->tri_rec.p;
     v->world_root = s->world_root;
@@ -796,6 +860,22 @@ extern "C" int chunky_render_set_option(chunky_render* r, int option, int32_t va
             break;
         case CHUNKY_OPT_EMITTER_SCALE: r->opts.emitter_scale = bits_to_float(value); break;
         case CHUNKY_OPT_KERNEL: r->kernel_variant = value; break;
+        case CHUNKY_OPT_SUN_SAMPLING:
+            if (value < -1 || value > 1) return fail(CHUNKY_E_INVALID, "sun sampling: -1 (as the reference), 0 or 1");
+            r->opts.sun_sampling = value;
+            break;
+        case CHUNKY_OPT_EMITTERS:
+            if (value != 0 && value != 1) return fail(CHUNKY_E_INVALID, "emitters: 0 or 1");
+            r->opts.emitters = value;
+            break;
+        case CHUNKY_OPT_BSDF:
+            if (value != 0 && value != 1) return fail(CHUNKY_E_INVALID, "bsdf: 0 or 1");
+            r->opts.bsdf = value;
+            break;
+        case CHUNKY_OPT_EMITTER_NEE:
+            if (value != 0 && value != 1) return fail(CHUNKY_E_INVALID, "emitter NEE: 0 or 1");
+            r->opts.nee = value;
+            break;
         default: return fail(CHUNKY_E_INVALID, "unknown option %d", option);
     }
     return CHUNKY_OK;
@@ -859,6 +939,11 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
     if (!r->have_camera) return fail(CHUNKY_E_STATE, "render_passes before set_camera");
     SceneView S;
     if (int rc = scene_view(r->scene, &S)) return rc;
+    if (opts_extended(r->opts)) {  // the extensions exist in render_pool only
+        const bool bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
+        if ((r->kernel_variant & (1 | 2 | 4 | 8)) || (bvh && !(S.bvh_rec && S.tri_rec && S.mat8)))
+            return fail(CHUNKY_E_STATE, "the extended light-transport options need the default kernel (CHUNKY_OPT_KERNEL 0)");
+    }
     if (r->pending.size() > 4096)
         if (int rc = collect_timing(r)) return rc;
     // render_pool stages every sample of a launch (12 bytes each): at most kStagingBytes of it, and fewer than 2^31 samples
@@ -927,6 +1012,7 @@ extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]) {
     out8[2] = r->last_choice.bvh;
     out8[3] = r->last_choice.blocks;
     out8[4] = r->last_choice.pool;
+    out8[5] = r->last_choice.ext;
     return CHUNKY_OK;
 }
 

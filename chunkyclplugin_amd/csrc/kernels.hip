@@ -324,6 +324,11 @@ struct LaneState {
     // stay inside the top cell of the step before (8^3 blocks): those skip the first of the two dependent reads
     int top_idx, top_e;
     int pid;  // render_pool with entity BVHs: which of the wave's to-visit stacks (LDS) belongs to this path
+    // extended integrator: what the current trace is — 0 the path's ray, 1 the sun shadow ray, 2 the
+    // emitter shadow ray — the light that ray brings if it is free, and whether the vertex before sampled the emitters
+    unsigned tkind : 2;
+    unsigned after_nee : 1;
+    f3 pend;
     // main record
     Hit h;
 };
@@ -439,6 +444,7 @@ DEV int block_phase(const SceneView& S, LaneState& L) {
         L.h.normal = t.normal;
         L.h.color = t.color;
         L.h.emittance = t.emittance;
+        L.h.spec = t.spec;
     }
     if (dist == dist) {
         if (!L.shadow) {
@@ -714,6 +720,158 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
     }
     part_end<PROF>(pt, PT_SAMPLING);
     return finished ? ST_NEXT : ST_SETUP;
+}
+
+// cosine-weighted direction about n from two draws — the direction part of nextPath (K/kernel.h:52-90), as diffuse_bounce
+DEV f3 cosine_direction(f3 n, float x1, float x2) {
+    float r = rt_sqrt(x1);
+    float theta = 2 * RT_PI_F * x2;
+    float st, ct;
+    rt_sincos(theta, &st, &ct);
+    float tx = r * ct, ty = r * st, tz = rt_sqrt(1 - x1);
+    float xx, xy, xz = 0;
+    if ((double)rt_fabs(n.x) > 0.1) {
+        xx = 0;
+        xy = 1;
+    } else {
+        xx = 1;
+        xy = 0;
+    }
+    float ux = xy * n.z - xz * n.y;
+    float uy = xz * n.x - xx * n.z;
+    float uz = xx * n.y - xy * n.x;
+    r = 1 / rt_sqrt(ux * ux + uy * uy + uz * uz);
+    ux *= r;
+    uy *= r;
+    uz *= r;
+    float vx = uy * n.z - uz * n.y;
+    float vy = uz * n.x - ux * n.z;
+    float vz = ux * n.y - uy * n.x;
+    return f3{ux * tx + vx * ty + n.x * tz, uy * tx + vy * ty + n.y * tz, uz * tx + vz * ty + n.z * tz};
+}
+
+// SHADE of the EXTENDED integrator: oracle/port.c trace_sample_ext, operation for operation, as a
+// state machine over the kind of trace that just ended (L.tkind: 0 the path's ray, 1 the sun shadow ray, 2 the emitter
+// shadow ray).  Returns ST_SETUP (a ray is ready to be traced) or ST_NEXT (the path is finished).
+template <int TREE, bool BVH>
+DEV int shade_phase_ext(const SceneView& S, const RenderOpts& O, LaneState& L) {
+    const bool hit = BVH ? L.trace_hit : L.oct_hit;
+    const int kind = L.tkind;
+    const f3 n = L.h.normal;
+    int next = 0;  // 1 sun sampling, 2 emitter sampling, 3 diffuse bounce, 4 specular bounce (ray already set)
+    if (kind == 0) {
+        if (!hit) {
+            L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, 1.0f);
+            return ST_NEXT;
+        }
+        const f3 d_in = L.d;
+        L.o = L.o + L.d * (L.h.distance - kOffset);  // rec.point
+        const f3 base = L.throughput;
+        const f3 c = mk3(L.h.color.x, L.h.color.y, L.h.color.z);
+        const f3 thr_d = base * c;
+        if (O.emitters && !L.after_nee) L.radiance = L.radiance + (c * (L.h.emittance * O.emitter_scale)) * thr_d;
+        L.after_nee = false;
+        bool specular = false;
+        float metal = 0, rough = 0;
+        if (O.bsdf) {
+            const float spec = rt_unorm8((unsigned)L.h.spec & 0xFFu);
+            metal = rt_unorm8(((unsigned)L.h.spec >> 8) & 0xFFu);
+            rough = rt_unorm8(((unsigned)L.h.spec >> 16) & 0xFFu);
+            const float ps = rt_fmax(spec, metal);
+            if (ps > 0) specular = rt_pcg_float(&L.rng) < ps;
+        }
+        if (specular) {
+            L.throughput = mk3(base.x * (c.x * metal + (1 - metal)), base.y * (c.y * metal + (1 - metal)), base.z * (c.z * metal + (1 - metal)));
+            f3 refl = d_in - n * (2 * dot(d_in, n));
+            if (rough > 0) {
+                const float x1 = rt_pcg_float(&L.rng), x2 = rt_pcg_float(&L.rng);
+                const f3 dd = cosine_direction(n, x1, x2);
+                refl = normalize(dd * rough + refl * (1 - rough));
+                const float rn = dot(refl, n);
+                if (rn < 0) refl = refl - n * (2 * rn);
+            }
+            L.d = refl;
+            L.o = L.o + refl * kOffset;
+            next = 4;
+        } else {
+            L.throughput = thr_d;
+            next = 1;
+        }
+    } else if (kind == 1) {
+        if (!hit) L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, L.h.emittance);
+        next = 2;
+    } else {
+        if (!hit) L.radiance = L.radiance + L.pend;
+        next = 3;
+    }
+    if (next == 1) {  // Sun_sampleDirection + shadow ray (K/sky.h:68-93, K/rayTracer.cl:101-106): the record keeps its distance
+        const bool sun_on = O.sun_sampling < 0 ? (S.sun_flags & 1) != 0 : O.sun_sampling != 0;
+        if (sun_on) {
+            L.d = sun_sample(S, L.rng);
+            L.h.emittance = rt_fabs(dot(L.d, n));
+            L.tkind = 1;
+            L.shadow = true;
+            return ST_SETUP;
+        }
+        next = 2;
+    }
+    if (next == 2) {
+        next = 3;
+        // not at the last vertex: the bounce ray that would find the same light implicitly is never traced there
+        if (O.nee && O.emitters && S.n_emitters > 0 && (int)L.depth + 1 < O.max_depth) {
+            const float xk = rt_pcg_float(&L.rng), xf = rt_pcg_float(&L.rng), xu = rt_pcg_float(&L.rng), xv = rt_pcg_float(&L.rng);
+            int k = (int)(xk * (float)S.n_emitters);
+            if (k > S.n_emitters - 1) k = S.n_emitters - 1;
+            int face = (int)(xf * 6.0f);
+            if (face > 5) face = 5;
+            const int4 em = S.emitters[k];
+            const int level = (em.w >> 25) & 15, block = em.w & 0x1FFFFFF;
+            const float size = (float)(1 << level);
+            const float a = xu * size, b = xv * size;
+            const float fa = a - rt_floor(a), fb = b - rt_floor(b);
+            const float ex = (float)em.x, ey = (float)em.y, ez = (float)em.z;
+            f3 pe, nf;
+            float tu, tv;
+            switch (face) {
+                case 0: pe = mk3(ex, ey + a, ez + b); nf = mk3(-1, 0, 0); tu = 1 - fb; tv = fa; break;
+                case 1: pe = mk3(ex + size, ey + a, ez + b); nf = mk3(1, 0, 0); tu = fb; tv = fa; break;
+                case 2: pe = mk3(ex + a, ey, ez + b); nf = mk3(0, -1, 0); tu = fa; tv = 1 - fb; break;
+                case 3: pe = mk3(ex + a, ey + size, ez + b); nf = mk3(0, 1, 0); tu = fa; tv = fb; break;
+                case 4: pe = mk3(ex + a, ey + b, ez); nf = mk3(0, 0, -1); tu = fa; tv = fb; break;
+                default: pe = mk3(ex + a, ey + b, ez + size); nf = mk3(0, 0, 1); tu = 1 - fa; tv = fb; break;
+            }
+            const f3 l = pe - L.o;
+            const float d2 = dot(l, l);
+            const float dist = rt_sqrt(d2);
+            const f3 dir = l * (1 / dist);
+            const float cs = dot(dir, n), cl = -dot(dir, nf);
+            L.after_nee = true;
+            if (cs > 0 && cl > 0 && dist > 0.002f) {
+                Hit er = L.h;
+                if (material_sample(S, S.blocks[block + 1], tu, tv, er) && er.emittance > 0) {
+                    const float w = (cs * cl) / (RT_PI_F * d2) * (6.0f * (float)S.n_emitters * (size * size));
+                    const f3 ce = mk3(er.color.x, er.color.y, er.color.z);
+                    const f3 le = ce * (ce * (er.emittance * O.emitter_scale));
+                    L.pend = L.throughput * (le * w);
+                    L.d = dir;
+                    L.h.distance = dist - 0.001f;  // anything nearer than the emitter's face hides it
+                    L.tkind = 2;
+                    L.shadow = true;
+                    return ST_SETUP;
+                }
+            }
+        }
+    }
+    if (next == 3) {
+        const float x1 = rt_pcg_float(&L.rng), x2 = rt_pcg_float(&L.rng);
+        L.d = cosine_direction(n, x1, x2);
+        L.o = L.o + L.d * kOffset;
+    }
+    L.depth += 1;
+    L.h.distance = rt_inf();
+    L.tkind = 0;
+    L.shadow = false;
+    return (int)L.depth < O.max_depth ? ST_SETUP : ST_NEXT;
 }
 
 // SHADE, part 2 for G = 1 (one lane per pixel), called from wave-uniform control flow (the pixel
@@ -1152,9 +1310,12 @@ DEV int phase_class(int st) {
     return st == ST_MARCH ? 0 : (st == ST_BLOCK ? 1 : (st == ST_DONE ? 3 : (st == ST_MODEL ? 4 : ((st == ST_BVH || st == ST_LEAF) ? 5 : 2))));
 }
 
-DEV void pool_pack(const LaneState& L, uint4 (&v)[8]) {
+template <int WORDS>
+DEV void pool_pack(const LaneState& L, uint4 (&v)[WORDS]) {
     const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.cand_level << 10) |
-                          ((unsigned)L.trace_hit << 14) | ((unsigned)L.bvh_which << 15) | ((unsigned)L.pid << 16);
+                          ((unsigned)L.trace_hit << 14) | ((unsigned)L.bvh_which << 15) | ((unsigned)L.pid << 16) |
+                          ((unsigned)L.tkind << 24) | ((unsigned)L.after_nee << 26);
+    if (WORDS > 8) v[WORDS - 1] = make_uint4(__float_as_uint(L.pend.x), __float_as_uint(L.pend.y), __float_as_uint(L.pend.z), (unsigned)L.h.spec);
     v[0] = make_uint4((unsigned)L.sidx, L.rng, misc, (unsigned)L.steps);
     v[1] = make_uint4(__float_as_uint(L.radiance.x), __float_as_uint(L.radiance.y), __float_as_uint(L.radiance.z), __float_as_uint(L.throughput.x));
     v[2] = make_uint4(__float_as_uint(L.throughput.y), __float_as_uint(L.throughput.z), __float_as_uint(L.o.x), __float_as_uint(L.o.y));
@@ -1164,10 +1325,16 @@ DEV void pool_pack(const LaneState& L, uint4 (&v)[8]) {
     v[6] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
     v[7] = make_uint4(__float_as_uint(L.h.color.x), __float_as_uint(L.h.color.y), __float_as_uint(L.h.color.z), __float_as_uint(L.h.emittance));
 }
-DEV void pool_unpack(LaneState& L, const uint4 (&v)[8]) {
+template <int WORDS>
+DEV void pool_unpack(LaneState& L, const uint4 (&v)[WORDS]) {
+    if (WORDS > 8) {
+        L.pend = mk3(__uint_as_float(v[WORDS - 1].x), __uint_as_float(v[WORDS - 1].y), __uint_as_float(v[WORDS - 1].z));
+        L.h.spec = (int)v[WORDS - 1].w;
+    }
+    L.tkind = (v[0].z >> 24) & 3u; L.after_nee = (v[0].z >> 26) & 1u;
     L.sidx = (int)v[0].x; L.rng = v[0].y; L.steps = (int)v[0].w;
     L.depth = v[0].z & 0xFFu; L.shadow = (v[0].z >> 8) & 1u; L.oct_hit = (v[0].z >> 9) & 1u; L.cand_level = (v[0].z >> 10) & 15u;
-    L.trace_hit = (v[0].z >> 14) & 1u; L.bvh_which = (v[0].z >> 15) & 1u; L.pid = (int)(v[0].z >> 16);
+    L.trace_hit = (v[0].z >> 14) & 1u; L.bvh_which = (v[0].z >> 15) & 1u; L.pid = (int)((v[0].z >> 16) & 0xFFu);
     L.bvh_cur = (int)v[5].x; L.bvh_top = (int)v[5].y; L.bvh_dist = __uint_as_float(v[5].z);
     L.radiance = mk3(__uint_as_float(v[1].x), __uint_as_float(v[1].y), __uint_as_float(v[1].z));
     L.throughput = mk3(__uint_as_float(v[1].w), __uint_as_float(v[2].x), __uint_as_float(v[2].y));
@@ -1197,7 +1364,7 @@ DEV void wave_lds_fence() {
 // rank through two small LDS arrays — slot and tag of the r-th parked path that comes in, tag of the r-th lane path that
 // goes out — written by everybody first and read after ONE fence; then each swapping lane reads its partner's eight
 // 16-byte groups in one burst and writes its own over them.
-template <int K>
+template <int K, int WORDS = 8>
 DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) {
     const bool done = st == ST_DONE;
     const bool out = phase_class(st) != X;
@@ -1217,14 +1384,14 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
     if (goes) {
         const int e = P.list[r_out];
         const int s = e & 0xFF;
-        uint4 mine[8], theirs[8];
-        pool_pack(L, mine);
+        uint4 mine[WORDS], theirs[WORDS];
+        pool_pack<WORDS>(L, mine);
 #pragma unroll
-        for (int g = 0; g < 8; g++) theirs[g] = P.park[g * K + s];
+        for (int g = 0; g < WORDS; g++) theirs[g] = P.park[g * K + s];
 #pragma unroll
-        for (int g = 0; g < 8; g++) P.park[g * K + s] = mine[g];
+        for (int g = 0; g < WORDS; g++) P.park[g * K + s] = mine[g];
         st = e >> 8;
-        pool_unpack(L, theirs);
+        pool_unpack<WORDS>(L, theirs);
         L.top_idx = -1;  // the cached top-level entry belonged to the path that left
     }
     wave_lds_fence();  // the next swap's readers (other lanes) come after these writes
@@ -1319,6 +1486,7 @@ DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) {
                             if (!L.shadow) {
                                 L.h.color = t.color;
                                 L.h.emittance = t.emittance;
+                                L.h.spec = t.spec;
                                 L.h.normal = mk3(as_float(r3.x), as_float(r3.y), as_float(r3.z));
                                 L.h.distance = tt;
                             } else {
@@ -1384,8 +1552,9 @@ constexpr int kWWalk = CHUNKY_W_WALK, kWBvh = CHUNKY_W_BVH, kWLeaf = CHUNKY_W_LE
 #ifndef CHUNKY_POOL_BVH_WAVES
 #define CHUNKY_POOL_BVH_WAVES 5
 #endif
-template <int TREE, int K, bool STATS, bool BVH = false>
-__global__ void __launch_bounds__(256, (STATS ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
+template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false>
+__global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
+    constexpr int WORDS = EXT ? 9 : 8;  // 16-byte words of a parked path
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -1394,11 +1563,11 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES
     {
         // per wave: K parked records, their tag / list scratch, then (BVH) one to-visit stack per path of the pool
         const unsigned depth = BVH ? fresh_args()->stack_bytes : 0u;  // entries per stack
-        char* base = (char*)lds + wave * (K * 128 + K * 8 + (64 + K) * depth * 4);
+        char* base = (char*)lds + wave * (K * 16 * WORDS + K * 8 + (64 + K) * depth * 4);
         P.park = (uint4*)base;
-        P.tags = (int*)(base + K * 128);
+        P.tags = (int*)(base + K * 16 * WORDS);
         P.list = P.tags + K;
-        stacks.base = (int*)(base + K * 128 + K * 8);
+        stacks.base = (int*)(base + K * 16 * WORDS + K * 8);
         if (BVH && lane < K) P.park[lane] = make_uint4(0u, 0u, (unsigned)(64 + lane) << 16, 0u);  // the parked slots' stack ids
     }
     LdsStack stack{lds, 0};  // render_waves' per-lane stacks are not used here
@@ -1416,6 +1585,10 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES
     L.top_idx = -1;
     L.top_e = 0;
     L.pid = lane;
+    L.tkind = 0;
+    L.after_nee = false;
+    L.pend = mk3(0, 0, 0);
+    L.h.spec = 0;
     L.mean = mk3(0, 0, 0);
     L.slot = 0;
     L.serial = 0;
@@ -1470,7 +1643,7 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         if (K > 0) {
-            const int n = pool_swap<K>(P, L, st, ptag, X, lane);
+            const int n = pool_swap<K, WORDS>(P, L, st, ptag, X, lane);
             if (STATS && n) {
                 swap_rounds += 1;
                 swapped += (unsigned long long)n;
@@ -1567,7 +1740,7 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES
             WaveArgPtr A = fresh_args();
             const SceneView S = arg_copy(&A->S);
             const RenderOpts O = arg_copy(&A->O);
-            if (st == ST_SHADE) st = shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
+            if (st == ST_SHADE) st = EXT ? shade_phase_ext<TREE, BVH>(S, O, L) : shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
             part_begin<STATS>(&parts);
             if (st == ST_NEXT) {  // the path is finished: its radiance waits in the staging array for fold_kernel
                 // streamed past the caches (nt): written once, read once by fold_kernel; the L2 stays with the tree
@@ -1607,6 +1780,8 @@ __global__ void __launch_bounds__(256, (STATS ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES
                         L.throughput = mk3(1, 1, 1);
                         L.depth = 0;
                         L.shadow = false;
+                        L.tkind = 0;
+                        L.after_nee = false;
                         L.h.distance = rt_inf();
                         st = ST_SETUP;
                     }
@@ -1908,7 +2083,17 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     if (const char* e = getenv("CHUNKY_DEBUG_POOL")) park = atoi(e);
     typedef void (*Kernel)(WaveArgs);
     Kernel k;
-    if (bvh) {
+    const bool ext = opts_extended(O);  // EXPERIMENTAL light-transport options: their own instantiations
+    int words = 8;
+    if (ext) {
+        if (tree != 17 && tree != 18) tree = -1;
+        words = 9;
+        park = bvh ? 16 : 32;
+        if (bvh)
+            k = tree == 17 ? render_pool<17, 16, false, true, true> : (tree == 18 ? render_pool<18, 16, false, true, true> : render_pool<-1, 16, false, true, true>);
+        else
+            k = tree == 17 ? render_pool<17, 32, false, false, true> : (tree == 18 ? render_pool<18, 32, false, false, true> : render_pool<-1, 32, false, false, true>);
+    } else if (bvh) {
         // every path of the pool owns a to-visit stack in LDS: 32 parked paths when five workgroups per CU still fit, else 16
         if (tree != 17 && tree != 18) tree = -1;
         park = 5 * 4 * (32 * 136 + (64 + 32) * depth * 4) <= 160 * 1024 ? 32 : 16;
@@ -1940,7 +2125,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
             default: tree = -1; k = render_pool<-1, kPoolPark, false>; break;
         }
     }
-    const size_t lds = (size_t)(block / 64) * (size_t)(park * 128 + park * 8 + (64 + park) * depth * 4);
+    const size_t lds = (size_t)(block / 64) * (size_t)(park * 16 * words + park * 8 + (64 + park) * depth * 4);
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
     if (e != hipSuccess) return e;
@@ -1950,7 +2135,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     const long long want = (n_samples + (long long)(block / 64) * (64 + park) - 1) / ((long long)(block / 64) * (64 + park));
     int grid = n_cu * bpc;
     if ((long long)grid > want) grid = (int)want;
-    if (chosen) *chosen = KernelChoice{tree, 1, bvh ? 1 : 0, grid, park};
+    if (chosen) *chosen = KernelChoice{tree, 1, bvh ? 1 : 0, grid, park, ext ? 1 : 0};
     e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
     WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)depth, staging, (unsigned)n_samples};
@@ -2061,7 +2246,7 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         int grid = n_cu * bpc;
         if ((long long)grid > want) grid = (int)want;
         if (grid <= 0 || P.n <= 0) return hipSuccess;
-        if (chosen) *chosen = KernelChoice{tree, group, has_bvh ? 1 : 0, grid, -1};
+        if (chosen) *chosen = KernelChoice{tree, group, has_bvh ? 1 : 0, grid, -1, 0};
         e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
         WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)stack, nullptr, 0u};
@@ -2071,7 +2256,7 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
     const int block = 256;
     int grid = (T.n_local + block - 1) / block;
     if (grid <= 0 || P.n <= 0) return hipSuccess;
-    if (chosen) *chosen = KernelChoice{use_wide(variant, S) ? -1 : 0, 0, any_bvh ? 1 : 0, grid, -1};
+    if (chosen) *chosen = KernelChoice{use_wide(variant, S) ? -1 : 0, 0, any_bvh ? 1 : 0, grid, -1, 0};
     if (use_wide(variant, S))
         hipLaunchKernelGGL(render_lanes<-1>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
     else

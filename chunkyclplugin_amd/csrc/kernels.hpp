@@ -46,6 +46,7 @@ struct KernelChoice {
     int bvh;     // entity-BVH phases compiled in
     int blocks;  // workgroups launched
     int pool;    // render_pool: paths parked per wave beside the 64 in its lanes; -1 = another kernel
+    int ext;     // the extended integrator (CHUNKY_OPT_SUN_SAMPLING / _EMITTERS / _BSDF / _EMITTER_NEE at non-default values)
 };
 // staging floats render_pool needs for a launch of n passes over n_local pixel slots
 inline size_t staging_floats(int n_local, int n_passes) { return 3 * (size_t)n_local * (size_t)n_passes; }

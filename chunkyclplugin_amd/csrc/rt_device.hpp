@@ -83,9 +83,9 @@ struct SceneView {
     const uint4* __restrict__ cube_info;
     // 16-byte-aligned re-layouts built at upload (capi.hip rebuild_derived); block_info word 7 of a model block =
     // first record << 8 | primitive count, 0 = none (the packed palettes are read as they are):
-    //   mat8      per material two words {flags, tint, textureSize, color} {normal_emittance, 0, 0, 0}
+    //   mat8      per material two words {flags, tint, textureSize, color} {normal_emittance, word 5, 0, 0}
     //   aabb_rec  per box three words {xmin, xmax, ymin, ymax} {zmin, zmax, flags, E} {S, W, T, B} (materials = mat8 indices)
-    //   quad_rec  per quad six words {o, dot(n, o)} {xv, |xv|^2} {yv, |yv|^2} {uv} {n, normal_emittance} {flags, tint, textureSize, color}
+    //   quad_rec  per quad six words {o, dot(n, o)} {xv, |xv|^2} {yv, |yv|^2} {uv} {n, emittance byte | word 5 << 8} {flags, tint, textureSize, color}
     const int4* __restrict__ mat8;
     const int4* __restrict__ aabb_rec;
     const int4* __restrict__ quad_rec;
@@ -97,6 +97,10 @@ struct SceneView {
     const int4* __restrict__ bvh_rec;
     const int4* __restrict__ tri_rec;
     int world_root, actor_root;  // reference of each BVH's root
+    // emitter next-event estimation (extension): every emitter leaf of the octree as {x, y, z, level << 25 | block pointer},
+    // in pre-order — the list of oracle/port.c port_list_emitters
+    const int4* __restrict__ emitters;
+    int n_emitters;
 };
 
 struct CameraView {
@@ -112,7 +116,14 @@ struct RenderOpts {
     int draw_depth;       // 256, K/rayTracer.cl:94
     int max_depth;        // 5,   K/rayTracer.cl:107
     float emitter_scale;  // 13,  K/rayTracer.cl:99
+    // EXPERIMENTAL light-transport options (specification: oracle/port.c trace_sample_ext).  The
+    // defaults are the reference's behaviour and select the reference kernels.
+    int sun_sampling;     // -1 as the reference (PackedSun flag bit 0), 0 never, 1 always
+    int emitters;         // 1 as the reference; 0 = emittersEnabled false
+    int bsdf;             // 1: specular / metal / roughness from material word 5
+    int nee;              // 1: emitter next-event estimation
 };
+__host__ __device__ inline bool opts_extended(const RenderOpts& O) { return O.sun_sampling != -1 || O.emitters != 1 || O.bsdf != 0 || O.nee != 0; }
 
 // Per-path state: Pixel + Ray + IntersectionRecord of K/wavefront.h:6-51, flattened.
 struct Hit {
@@ -121,6 +132,7 @@ struct Hit {
     f3 normal;
     f4 color;
     float emittance;
+    int spec;  // material word 5 (spec | metal << 8 | rough << 16): only the extended integrator reads it
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -184,13 +196,13 @@ __device__ __constant__ const float kEmittanceLut[256] = {
 // K/material.h:31-82.  `shade` = false skips the writes that only matter to the main record
 // (shadow rays need the accept/reject decision only).
 DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsigned tex_size, unsigned color_w,
-                       unsigned ne, float u, float v, Hit& h);
+                       unsigned ne, float u, float v, Hit& h, int m5 = 0);
 DEV bool material_sample(const SceneView& S, int material, float u, float v, Hit& h) {
     const int* m = S.materials + material;
-    return material_eval(S, m[0], m[1], m[2], m[3], m[4], u, v, h);
+    return material_eval(S, m[0], m[1], m[2], m[3], m[4], u, v, h, m[5]);
 }
 DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsigned tex_size, unsigned color_w,
-                       unsigned ne, float u, float v, Hit& h) {
+                       unsigned ne, float u, float v, Hit& h, int m5) {
     f4 c = (flags & 4) ? unpack_unorm8(atlas_texel(S, u, v, (int)color_w, (int)tex_size)) : color_from_argb(color_w);
     if (!(c.w > kEps)) return false;
     unsigned tt = tint >> 24;
@@ -204,6 +216,7 @@ DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsign
         h.emittance = unpack_unorm8(atlas_texel(S, u, v, (int)ne, (int)tex_size)).w;
     else
         h.emittance = kEmittanceLut[ne & 0xFF];  // double site K/material.h:79, tabulated
+    h.spec = m5;
     return true;
 }
 
@@ -241,13 +254,13 @@ DEV Face face_map2(const Slabs& s, float tmin, f3 p) {  // AABB_full_intersect_m
 // position `pos` where a direction is expected (K/block.h:52), so the UV point is no + tmin*pos.
 // The material arrives as its 5 words (read from the material palette, or inline in block_info).
 DEV float cube_hit(const SceneView& S, unsigned m0, unsigned m1, unsigned m2, unsigned m3, unsigned m4, f3 no, f3 pos,
-                   f3 inv, Hit& h) {
+                   f3 inv, Hit& h, int m5 = 0) {
     Slabs s = slabs(0, 1, 0, 1, 0, 1, no, inv);
     float tn = slab_near(s), tf = slab_far(s);
     if (tf < tn) return rt_nan();
     Face f = face_unit(s, tn, no + pos * tn);
     h.normal = f.n;  // written before the material test (K/block.h:59-60)
-    return material_eval(S, m0, m1, m2, m3, m4, f.u, f.v, h) ? tn - kOffset : rt_nan();
+    return material_eval(S, m0, m1, m2, m3, m4, f.u, f.v, h, m5) ? tn - kOffset : rt_nan();
 }
 
 // AABB model (type 2) — K/block.h:66-91, K/primitives.h:165-260
@@ -333,7 +346,7 @@ DEV float quad_model_hit(const SceneView& S, int ptr, f3 no, f3 dir, Hit& h) {
 
 DEV bool material_sample8(const SceneView& S, int m8, float u, float v, Hit& h) {
     const int4 a = S.mat8[m8], b = S.mat8[m8 + 1];
-    return material_eval(S, a.x, a.y, a.z, a.w, b.x, u, v, h);
+    return material_eval(S, a.x, a.y, a.z, a.w, b.x, u, v, h, b.y);
 }
 
 // aabb_model_hit / quad_model_hit on the aligned records (same arithmetic, same order; rec = first record << 8 | count)
@@ -392,7 +405,7 @@ DEV float quad_model_hit_rec(const SceneView& S, int rec, f3 no, f3 dir, Hit& h)
         const int4 r3 = q[3], r5 = q[5];
         float tu = as_float(r3.x) + (u * as_float(r3.y));
         float tv = as_float(r3.z) + (v * as_float(r3.w));
-        if (material_eval(S, r5.x, r5.y, r5.z, r5.w, r4.w, tu, tv, h)) {
+        if (material_eval(S, r5.x, r5.y, r5.z, r5.w, r4.w, tu, tv, h, (int)((unsigned)r4.w >> 8))) {  // r4.w = emittance byte | word 5 << 8
             h.normal = n;
             best = t;
             hit = true;
@@ -410,14 +423,14 @@ DEV float block_hit(const SceneView& S, int block, int bx, int by, int bz, f3 po
         const int4 a = S.block_info[(unsigned)block], b = S.block_info[(unsigned)block + 1u];
         type = a.x;
         ptr = a.y;
-        if (type == 1) return cube_hit(S, a.z, a.w, b.x, b.y, b.z, no, pos, inv, h);
+        if (type == 1) return cube_hit(S, a.z, a.w, b.x, b.y, b.z, no, pos, inv, h, b.w);  // word 7 of a cube: material word 5
         if (b.w != 0) return type == 2 ? aabb_model_hit_rec(S, b.w, no, dir, inv, h) : quad_model_hit_rec(S, b.w, no, dir, h);
     } else {
         type = S.blocks[block];
         ptr = S.blocks[block + 1];
         if (type == 1) {
             const int* m = S.materials + ptr;
-            return cube_hit(S, m[0], m[1], m[2], m[3], m[4], no, pos, inv, h);
+            return cube_hit(S, m[0], m[1], m[2], m[3], m[4], no, pos, inv, h, m[5]);
         }
     }
     switch (type) {

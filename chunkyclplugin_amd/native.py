@@ -27,7 +27,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("material", "<i4"), ("distance", "<f4"), 
 
 PALETTE_BLOCK, PALETTE_MATERIAL, PALETTE_AABB, PALETTE_QUAD, PALETTE_TRIG = range(5)
 BVH_WORLD, BVH_ACTOR = 0, 1
-OPT_DRAW_DEPTH, OPT_MAX_DEPTH, OPT_EMITTER_SCALE, OPT_KERNEL = range(4)
+OPT_DRAW_DEPTH, OPT_MAX_DEPTH, OPT_EMITTER_SCALE, OPT_KERNEL, OPT_SUN_SAMPLING, OPT_EMITTERS, OPT_BSDF, OPT_EMITTER_NEE = range(8)
 E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_ABORTED = -1, -2, -3, -4, -5
 
 
@@ -106,6 +106,7 @@ def lib() -> C.CDLL:
             "chunky_scene_write_atlas_tile": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp],
             "chunky_scene_set_sky": [vp, vp, C.c_int, C.c_int, f32],
             "chunky_scene_set_sun": [vp, vp],
+            "chunky_scene_emitters": [vp, vp, i32, C.POINTER(i32)],
             "chunky_render_create": [vp, vp, C.c_int, C.c_int, C.POINTER(vp)],
             "chunky_render_destroy": [vp],
             "chunky_render_set_camera": [vp, C.c_int, vp, i64],

@@ -102,6 +102,14 @@ class HipSceneLoader:
         self.packed = sc
         return True
 
+    def emitters(self) -> np.ndarray:
+        """The emitter list of the next-event-estimation extension: rows {x, y, z, level << 25 | block pointer}."""
+        n = C.c_int32()
+        check(native.lib().chunky_scene_emitters(self._h, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 4), np.int32)
+        check(native.lib().chunky_scene_emitters(self._h, ptr(out), n.value, C.byref(n)))
+        return out[:n.value]
+
     def load_octree(self, tree_data, depth: int, block_mapping) -> None:
         """`ClSceneLoader.loadOctree` (ClSceneLoader.java:52-63): raw PackedOctree.treeData +
         blockMapping, remapped natively."""
@@ -186,7 +194,8 @@ class HipPathTracingRenderer:
         """The kernel instantiation the last launch ran: tree form, lanes per pixel, entity-BVH phases, workgroups."""
         out = np.zeros(8, np.int32)
         check(native.lib().chunky_render_kernel_info(self._h, ptr(out)))
-        return {"tree": int(out[0]), "group": int(out[1]), "bvh": bool(out[2]), "blocks": int(out[3]), "pool": int(out[4])}
+        return {"tree": int(out[0]), "group": int(out[1]), "bvh": bool(out[2]), "blocks": int(out[3]), "pool": int(out[4]),
+                "ext": bool(out[5])}
 
     def phase_stats(self, reset: bool = True) -> dict:
         out = np.zeros(24, np.uint64)

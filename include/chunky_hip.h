@@ -82,6 +82,10 @@ int chunky_scene_set_atlas(chunky_scene* scene, const uint8_t* rgba, int width, 
 int chunky_scene_write_atlas_tile(chunky_scene* scene, int x, int y, int layer, int w, int h, const uint8_t* rgba);
 /* getSky(): skyTexture RGBA8 [h][w][4] + skyIntensity (ClSky.java:28-30,43-61) */
 int chunky_scene_set_sky(chunky_scene* scene, const uint8_t* rgba, int width, int height, float intensity);
+/* The emitter list CHUNKY_OPT_EMITTER_NEE samples (no reference counterpart): every octree leaf whose block is a full cube
+ * with a non-zero emittance byte, in pre-order, 4 ints each {x, y, z, level << 25 | block pointer}.  *count receives the
+ * number of emitters; at most `cap` are written. */
+int chunky_scene_emitters(chunky_scene* scene, int32_t* out4, int32_t cap, int32_t* count);
 /* getSun(): flags, textureSize, textureLocation, intensity, altitude, azimuth (PackedSun.java:32-41) */
 int chunky_scene_set_sun(chunky_scene* scene, const int32_t sun[6]);
 
@@ -96,10 +100,18 @@ typedef enum chunky_option {
     CHUNKY_OPT_DRAW_DEPTH = 0,      /* int, default 256  (K/rayTracer.cl:94) */
     CHUNKY_OPT_MAX_DEPTH = 1,       /* int >= 1, default 5 (K/rayTracer.cl:107) */
     CHUNKY_OPT_EMITTER_SCALE = 2,   /* float bits, default 13.0f (K/rayTracer.cl:99) */
-    CHUNKY_OPT_KERNEL = 3           /* int: kernel variant, 0 = default; bit 0 reference octree layout, bit 1 one lane
+    CHUNKY_OPT_KERNEL = 3,          /* int: kernel variant, 0 = default; bit 0 reference octree layout, bit 1 one lane
                                      * per path, bit 2 phase profile, bit 3 the grouped kernel instead of the pool kernel,
                                      * bits 4-5 (grouped kernel) lanes per pixel 1/8/16, bits 6-7 (pool kernel) paths parked
                                      * per wave none/32/64 instead of 48 (all bit-identical) */
+    /* EXPERIMENTAL light-transport extensions (the reference has none of them — it gates sun
+     * sampling on drawTexture, PackedSun.java:16 / K/sky.h:69, ignores emittersEnabled, and loads material word 5 without
+     * using it, K/material.h:38).  Specification: oracle/port.c trace_sample_ext; DESIGN.md section 9.  The defaults are the
+     * reference's behaviour and run the reference kernels. */
+    CHUNKY_OPT_SUN_SAMPLING = 4,    /* int: -1 as the reference (PackedSun flag bit 0), 0 never, 1 always (Chunky sunEnabled) */
+    CHUNKY_OPT_EMITTERS = 5,        /* int: 1 (default) / 0 = Chunky emittersEnabled false */
+    CHUNKY_OPT_BSDF = 6,            /* int: 0 (default) / 1 = specular, metalness, roughness from material word 5 (PackedMaterial.java:69-71) */
+    CHUNKY_OPT_EMITTER_NEE = 7      /* int: 0 (default) / 1 = next-event estimation towards the scene's emitter blocks */
 } chunky_option;
 int chunky_render_set_option(chunky_render* r, int option, int32_t value);
 
@@ -131,7 +143,7 @@ int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches);
  * tests assert it, so that a comparison with the oracle is a comparison of the kernel that is timed): out8 =
  * {tree form: 0 reference octree layout (K/octree.h:81-89), -1 generic wide tree, 16 + n dense top node over n levels
  * of 8x8x8 nodes; lanes per pixel (0 = one lane per pixel for the whole launch); entity-BVH phases present (K/bvh.h:22-113);
- * workgroups launched; paths parked per wave (pool kernel; -1 = the grouped kernel); 3 reserved}. */
+ * workgroups launched; paths parked per wave (pool kernel; -1 = the grouped kernel); extended integrator; 2 reserved}. */
 int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]);
 
 /* Profile of the wave-scheduled kernel, filled only while CHUNKY_OPT_KERNEL has bit 2 set: for each of

@@ -173,6 +173,37 @@ class PortOptions:
         return False
 
 
+class PortExt:
+    """with PortExt(port, scene, sun_sampling=.., emitters=.., bsdf=.., nee=..): the C restatement renders with the
+    EXPERIMENTAL light-transport options of DESIGN.md section 9 (oracle/port.c trace_sample_ext is their specification);
+    the emitter list the NEE option samples is built here by port_list_emitters.  Defaults restored on exit."""
+
+    def __init__(self, port, sc, sun_sampling=-1, emitters=1, bsdf=0, nee=0):
+        self.port, self.args = port, (int(sun_sampling), int(emitters), int(bsdf), int(nee))
+        self.handle = sc if isinstance(sc, SceneHandle) else SceneHandle(sc)
+        L = port.lib
+        L.port_set_ext.argtypes = [C.c_int] * 4
+        L.port_set_ext.restype = None
+        L.port_list_emitters.argtypes = [C.POINTER(OracleScene), C.c_void_p, C.c_int]
+        L.port_list_emitters.restype = C.c_int
+        L.port_use_emitters.argtypes = [C.c_void_p, C.c_int]
+        L.port_use_emitters.restype = None
+        n = L.port_list_emitters(C.byref(self.handle.struct), None, 0)
+        self.emitters = np.zeros((max(n, 1), 4), np.int32)
+        L.port_list_emitters(C.byref(self.handle.struct), _ptr(self.emitters), n)
+        self.n_emitters = n
+
+    def __enter__(self):
+        self.port.lib.port_use_emitters(_ptr(self.emitters), self.n_emitters)
+        self.port.lib.port_set_ext(*self.args)
+        return self
+
+    def __exit__(self, *exc):
+        self.port.lib.port_set_ext(-1, 1, 0, 0)
+        self.port.lib.port_use_emitters(None, 0)
+        return False
+
+
 class RefLib(_Lib):
     prefix = "ref"
 

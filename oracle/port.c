@@ -83,6 +83,7 @@ typedef struct {
     v3 normal, point;
     v4 color;
     float emittance;
+    int spec; /* material word 5 (spec | metal << 8 | rough << 16, PackedMaterial.java:69-71): read by the extensions only */
 } Record;
 
 typedef struct { /* K/sky.h:9-17 */
@@ -190,6 +191,7 @@ static int material_sample(const OracleScene* s, int material, Record* rec, floa
         rec->emittance = atlas_read_uv(s, u, v, (int)ne, (int)tex_size).w;
     else
         rec->emittance = (float)((ne & 0xFF) / 255.0); /* double site, material.h:79 */
+    rec->spec = m[5];
     return 1;
 }
 
@@ -688,6 +690,204 @@ static v3 trace_sample(const OracleScene* s, const Sun* sun, int seed, int gid, 
     return p.color;
 }
 
+/* ------------------------------------------------------------------------- extensions ------ */
+/* SURVEY.md section 8 row f2 / DESIGN.md section 9: light-transport options the north star names and the reference does
+ * not have.  EXPERIMENTAL — there is no reference implementation to pin them to; this restatement IS their
+ * specification, the HIP kernels must reproduce it bit for bit, and tests/test_extensions.py checks it analytically
+ * (energy conservation, mirror limit, NEE on/off means).  With every option at its default the reference path above runs.
+ *
+ *   sun_sampling  -1 as the reference (sample the sun iff PackedSun flag bit 0, K/sky.h:69), 0 never, 1 always — Chunky's
+ *                 sunEnabled, separated from drawTexture (which keeps gating the sun DISC, K/sky.h:45)
+ *   emitters      1 as the reference (emittance x emitter_scale at every hit, K/kernel.h:39-43), 0 Chunky's emittersEnabled = false
+ *   bsdf          1: material word 5 = spec | metal << 8 | rough << 16 (PackedMaterial.java:69-71, loaded and ignored by
+ *                 K/material.h:38).  With probability max(spec, metal) / 255 a hit reflects specularly: throughput *=
+ *                 lerp(1, colour, metal); direction = reflect(d, n), blended with a cosine sample by `rough`; no sun / emitter
+ *                 sampling at that vertex.  Otherwise the diffuse path of the reference.
+ *   nee           1: at every diffuse vertex one emitter block (uniform over the scene's emitter list), one of its six
+ *                 faces and a point on it are drawn; if the faces see each other and the segment is free, its radiance
+ *                 colour^2 x emittance x emitter_scale (what the implicit path adds on hitting it, K/kernel.h:39-43) is
+ *                 added with the area-measure weight cos cos / (pi d^2) x 6 N A.  The bounce ray that follows does not count
+ *                 an emitter it hits again; the last vertex of a path (whose bounce ray is never traced) samples none.
+ * Random draws per vertex, in this order: [1: specular?  only if max(spec, metal) > 0] then specular: [2 if rough > 0];
+ * diffuse: [2 sun if on] [4 emitter if on] 2 bounce. */
+typedef struct {
+    int sun_sampling, emitters, bsdf, nee;
+} Ext;
+static Ext g_ext = {-1, 1, 0, 0};
+void port_set_ext(int sun_sampling, int emitters, int bsdf, int nee) {
+    g_ext.sun_sampling = sun_sampling;
+    g_ext.emitters = emitters;
+    g_ext.bsdf = bsdf;
+    g_ext.nee = nee;
+}
+static int ext_active(void) { return g_ext.sun_sampling != -1 || g_ext.emitters != 1 || g_ext.bsdf != 0 || g_ext.nee != 0; }
+
+/* The emitter list: every octree leaf whose block is a full cube (model type 1) with a non-zero emittance byte and no
+ * emittance texture, in pre-order (children in index order), as {x, y, z, level << 25 | block pointer}: one box of edge
+ * 2^level per leaf.  Returns the number found (may exceed cap; only cap are written). */
+static int list_emitters(const OracleScene* s, int node, int x, int y, int z, int level, int32_t* out, int cap, int n) {
+    int v = s->octree[node];
+    if (v > 0) {
+        for (int c = 0; c < 8; c++) {
+            int h = 1 << (level - 1);
+            n = list_emitters(s, v + c, x + ((c >> 2) & 1) * h, y + ((c >> 1) & 1) * h, z + (c & 1) * h, level - 1, out, cap, n);
+        }
+        return n;
+    }
+    int block = -v;
+    if (block == 0 || block == ANY_TYPE) return n;
+    if (s->block_palette[block] != 1) return n;
+    const int32_t* m = s->material_palette + s->block_palette[block + 1];
+    if ((m[0] & 2) || (m[4] & 0xFF) == 0) return n;
+    if (n < cap) {
+        out[4 * n] = x; out[4 * n + 1] = y; out[4 * n + 2] = z;
+        out[4 * n + 3] = (level << 25) | block;
+    }
+    return n + 1;
+}
+int port_list_emitters(const OracleScene* s, int32_t* out4, int cap) {
+    return list_emitters(s, 0, 0, 0, 0, s->octree_depth, out4, cap, 0);
+}
+static const int32_t* g_emitters = 0;
+static int g_n_emitters = 0;
+void port_use_emitters(const int32_t* list4, int n) { g_emitters = list4; g_n_emitters = n; }
+
+/* cosine-weighted direction about n from two draws: the direction part of nextPath (K/kernel.h:52-90) */
+static v3 cosine_direction(v3 n, float x1, float x2) {
+    float r = rt_sqrt(x1);
+    float theta = 2 * RT_PI_F * x2;
+    float st, ct;
+    rt_sincos(theta, &st, &ct);
+    float tx = r * ct, ty = r * st, tz = rt_sqrt(1 - x1);
+    float xx, xy, xz = 0;
+    if ((double)rt_fabs(n.x) > 0.1) { xx = 0; xy = 1; } else { xx = 1; xy = 0; }
+    float ux = xy * n.z - xz * n.y;
+    float uy = xz * n.x - xx * n.z;
+    float uz = xx * n.y - xy * n.x;
+    r = 1 / rt_sqrt(ux * ux + uy * uy + uz * uz);
+    ux *= r; uy *= r; uz *= r;
+    float vx = uy * n.z - uz * n.y;
+    float vy = uz * n.x - ux * n.z;
+    float vz = ux * n.y - uy * n.x;
+    return V3(ux * tx + vx * ty + n.x * tz, uy * tx + vy * ty + n.y * tz, uz * tx + vz * ty + n.z * tz);
+}
+
+static v3 trace_sample_ext(const OracleScene* s, const Sun* sun, const Ext* x, int seed, int gid) {
+    Path p;
+    Record rec;
+    path_init(&p, &rec);
+    unsigned state = (unsigned)seed + (unsigned)gid;
+    rt_pcg_next(&state);
+    primary_ray(s, gid, &state, &p, 0);
+    COUNT(samples, 1);
+    int after_nee = 0; /* the vertex before sampled the emitters: one found by the bounce ray is not counted twice */
+    for (;;) {
+        int hit = closest_intersect(s, &p, &rec, g_draw_depth);
+        if (!hit) {
+            rec.emittance = 1;
+            intersect_sky(s, sun, &p, &rec);
+            break;
+        }
+        COUNT(hits, 1);
+        const v3 base = p.throughput;
+        const v3 c = V3(rec.color.x, rec.color.y, rec.color.z);
+        const v3 thr_d = mul3(base, c);
+        const v3 point = rec.point, n = rec.normal;
+        if (x->emitters && !after_nee)
+            p.color = add3(p.color, mul3(scale3(c, rec.emittance * g_emitter_scale), thr_d)); /* K/kernel.h:39-43 */
+        after_nee = 0;
+        int specular = 0;
+        float metal = 0, rough = 0;
+        if (x->bsdf) {
+            const float spec = rt_unorm8((unsigned)rec.spec & 0xFF);
+            metal = rt_unorm8(((unsigned)rec.spec >> 8) & 0xFF);
+            rough = rt_unorm8(((unsigned)rec.spec >> 16) & 0xFF);
+            const float ps = rt_fmax(spec, metal);
+            if (ps > 0) specular = rt_pcg_float(&state) < ps;
+        }
+        if (specular) {
+            p.throughput = V3(base.x * (c.x * metal + (1 - metal)), base.y * (c.y * metal + (1 - metal)), base.z * (c.z * metal + (1 - metal)));
+            const v3 d = p.direction;
+            v3 refl = sub3(d, scale3(n, 2 * dot3(d, n)));
+            if (rough > 0) {
+                float x1 = rt_pcg_float(&state), x2 = rt_pcg_float(&state);
+                v3 dd = cosine_direction(n, x1, x2);
+                refl = normalize3(add3(scale3(dd, rough), scale3(refl, 1 - rough)));
+                float rn = dot3(refl, n);
+                if (rn < 0) refl = sub3(refl, scale3(n, 2 * rn));
+            }
+            p.direction = refl;
+            p.origin = add3(point, scale3(refl, OFFSET));
+        } else {
+            p.throughput = thr_d;
+            p.origin = point;
+            const int sun_on = x->sun_sampling < 0 ? (sun->flags & 1) : x->sun_sampling;
+            if (sun_on) { /* Sun_sampleDirection + shadow trace, K/sky.h:68-93, K/rayTracer.cl:101-106 */
+                Sun on = *sun;
+                on.flags |= 1;
+                sun_sample_direction(&on, &p, &rec, &state);
+                Record shadow = rec;
+                shadow.point = rec.normal;
+                if (!closest_intersect(s, &p, &shadow, g_draw_depth)) intersect_sky(s, sun, &p, &shadow);
+            }
+            /* not at the last vertex: the bounce ray that would find the same light implicitly is never traced there */
+            if (x->nee && x->emitters && g_n_emitters > 0 && p.ray_depth + 1 < g_max_depth) {
+                const float xk = rt_pcg_float(&state), xf = rt_pcg_float(&state), xu = rt_pcg_float(&state), xv = rt_pcg_float(&state);
+                int k = (int)(xk * (float)g_n_emitters);
+                if (k > g_n_emitters - 1) k = g_n_emitters - 1;
+                int face = (int)(xf * 6.0f);
+                if (face > 5) face = 5;
+                const int32_t* em = g_emitters + 4 * k;
+                const int level = (em[3] >> 25) & 15, block = em[3] & 0x1FFFFFF;
+                const float size = (float)(1 << level);
+                const float a = xu * size, b = xv * size;
+                const float fa = a - rt_floor(a), fb = b - rt_floor(b);
+                const float ex = (float)em[0], ey = (float)em[1], ez = (float)em[2];
+                v3 pe, nf;
+                float tu, tv;
+                switch (face) {
+                    case 0: pe = V3(ex, ey + a, ez + b); nf = V3(-1, 0, 0); tu = 1 - fb; tv = fa; break;
+                    case 1: pe = V3(ex + size, ey + a, ez + b); nf = V3(1, 0, 0); tu = fb; tv = fa; break;
+                    case 2: pe = V3(ex + a, ey, ez + b); nf = V3(0, -1, 0); tu = fa; tv = 1 - fb; break;
+                    case 3: pe = V3(ex + a, ey + size, ez + b); nf = V3(0, 1, 0); tu = fa; tv = fb; break;
+                    case 4: pe = V3(ex + a, ey + b, ez); nf = V3(0, 0, -1); tu = fa; tv = fb; break;
+                    default: pe = V3(ex + a, ey + b, ez + size); nf = V3(0, 0, 1); tu = 1 - fa; tv = fb; break;
+                }
+                const v3 l = sub3(pe, point);
+                const float d2 = dot3(l, l);
+                const float dist = rt_sqrt(d2);
+                const v3 dir = scale3(l, 1 / dist);
+                const float cs = dot3(dir, n), cl = -dot3(dir, nf);
+                if (cs > 0 && cl > 0 && dist > 0.002f) {
+                    Record er;
+                    memset(&er, 0, sizeof er);
+                    if (material_sample(s, s->block_palette[block + 1], &er, tu, tv) && er.emittance > 0) {
+                        Path q = p;
+                        q.origin = point;
+                        q.direction = dir;
+                        Record sh = rec;
+                        sh.distance = dist - 0.001f; /* anything nearer than the emitter's face hides it */
+                        if (!closest_intersect(s, &q, &sh, g_draw_depth)) {
+                            const float w = (cs * cl) / (RT_PI_F * d2) * (6.0f * (float)g_n_emitters * (size * size));
+                            const v3 ce = V3(er.color.x, er.color.y, er.color.z);
+                            const v3 le = mul3(ce, scale3(ce, er.emittance * g_emitter_scale));
+                            p.color = add3(p.color, mul3(thr_d, scale3(le, w)));
+                        }
+                    }
+                }
+                after_nee = 1;
+            }
+            float x1 = rt_pcg_float(&state), x2 = rt_pcg_float(&state);
+            p.direction = cosine_direction(n, x1, x2);
+            p.origin = add3(point, scale3(p.direction, OFFSET));
+        }
+        p.ray_depth += 1;
+        rec.distance = rt_inf();
+        if (!(p.ray_depth < g_max_depth)) break;
+    }
+    return p.color;
+}
+
 /* ------------------------------------------------------------------------ entry points ----- */
 /* Host pass loop of OpenClPathTracingRenderer.java:102-144 around the accumulate of
  * K/rayTracer.cl:109-112: pass k uses seeds[k] and bufferSpp = first_spp + k. */
@@ -704,7 +904,7 @@ int port_render_passes(const OracleScene* s, const int32_t* seeds, int n_passes,
             t_ctr = g_count_enabled ? &local : 0;
 #pragma omp for schedule(dynamic, 256)
             for (int64_t gid = gid_begin; gid < gid_end; gid++) {
-                v3 c = trace_sample(s, &sun, seed, (int)gid, 0, 0);
+                v3 c = ext_active() ? trace_sample_ext(s, &sun, &g_ext, seed, (int)gid) : trace_sample(s, &sun, seed, (int)gid, 0, 0);
                 float* px = res + 3 * gid;
                 px[0] = (px[0] * spp + c.x) / (spp + 1);
                 px[1] = (px[1] * spp + c.y) / (spp + 1);
@@ -733,7 +933,7 @@ int port_render_gids(const OracleScene* s, const int32_t* seeds, int n_passes, i
             float* px = res + 3 * (int64_t)gid;
             for (int k = 0; k < n_passes; k++) {
                 int spp = first_spp + k;
-                v3 c = trace_sample(s, &sun, seeds[k], gid, 0, 0);
+                v3 c = ext_active() ? trace_sample_ext(s, &sun, &g_ext, seeds[k], gid) : trace_sample(s, &sun, seeds[k], gid, 0, 0);
                 px[0] = (px[0] * spp + c.x) / (spp + 1);
                 px[1] = (px[1] * spp + c.y) / (spp + 1);
                 px[2] = (px[2] * spp + c.z) / (spp + 1);
