@@ -109,7 +109,7 @@ struct chunky_render {
     int kernel_variant = 0;
     ShardView shard{0, 1, 256, 0};
     DevBuf own_fb, work_counter;
-    DevBuf staging;  // render_pool: one launch's samples, [pass][pixel slot][3] floats
+    DevBuf staging;  // render_pool: one launch's samples, [tile of 256 slots][pass][slot][3] floats
     float* fb = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // timing brackets of enqueued launches
     std::vector<hipEvent_t> free_events;
@@ -947,9 +947,9 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
     if (r->pending.size() > 4096)
         if (int rc = collect_timing(r)) return rc;
     // render_pool stages every sample of a launch (12 bytes each): at most kStagingBytes of it, and fewer than 2^31 samples
-    const int n_local = r->shard.n_local > 0 ? r->shard.n_local : 1;
-    int64_t cap = (int64_t)(kStagingBytes / 12) / n_local;
-    const int64_t cap31 = ((int64_t)1 << 31) / n_local - 1;
+    const int64_t n_slots = (int64_t)(staging_floats(r->shard.n_local, r->width, r->height, 1) / 3);  // padded tiles
+    int64_t cap = (int64_t)(kStagingBytes / 12) / n_slots;
+    const int64_t cap31 = ((int64_t)1 << 31) / n_slots - 1;
     if (cap > cap31) cap = cap31;
     if (cap > kMaxPassesPerLaunch) cap = kMaxPassesPerLaunch;
     if (cap < 1) cap = 1;
@@ -958,7 +958,7 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
         ps.n = (n - done) < (int)cap ? (n - done) : (int)cap;
         ps.first_spp = first_buffer_spp + done;
         memcpy(ps.seed, seeds + done, (size_t)ps.n * 4);
-        const size_t need = staging_floats(r->shard.n_local, ps.n) * sizeof(float);
+        const size_t need = staging_floats(r->shard.n_local, r->width, r->height, ps.n) * sizeof(float);
         if (r->staging.bytes < need) {  // grows to the largest launch seen; launches on the stream are ordered, so it is reused
             HIP_TRY(hipStreamSynchronize(r->ctx->stream));
             r->staging.release();

@@ -49,7 +49,11 @@ struct KernelChoice {
     int ext;     // the extended integrator (CHUNKY_OPT_SUN_SAMPLING / _EMITTERS / _BSDF / _EMITTER_NEE at non-default values)
 };
 // staging floats render_pool needs for a launch of n passes over n_local pixel slots
-inline size_t staging_floats(int n_local, int n_passes) { return 3 * (size_t)n_local * (size_t)n_passes; }
+// (16 x 16-pixel tiles with one rank, 256-slot runs with several: either way fewer than n_local + 32 * (width + height) + 512 slots)
+inline size_t staging_floats(int n_local, int width, int height, int n_passes) {
+    const size_t tiled = (size_t)((width + 15) / 16) * (size_t)((height + 15) / 16) * 256, runs = ((size_t)n_local + 255) / 256 * 256;
+    return 3 * (tiled > runs ? tiled : runs) * (size_t)n_passes;
+}
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream,

@@ -249,11 +249,125 @@ def load_scene(octree2_path: str, json_path: str = None, width: int = 1920, heig
                               height=height, name="octree2:" + octree2_path.split("/")[-1])
 
 
+# ---------------------------------------------------------------------------------------- entities
+# The scene JSON lists 4 188 entities (paintings, wall signs, banners, heads, standing signs) and 389 actors (armour
+# stands) by kind, position and orientation.  Their models and textures are Chunky's + Minecraft's (not available), so
+# each becomes a PROXY: one or a few flat-coloured boxes of about the real size at the real place, packed as triangles
+# (PackedTriangle.java:72-78) into a world BVH and an actor BVH (PackedBvhNode.java:16-31).  That is enough to exercise
+# the entity path of K/bvh.h on the benchmark scene's own entity distribution; it is not Chunky's geometry.
+ENTITY_KINDS = ("painting", "wallsign", "wall_banner", "head", "standing_banner", "sign", "skull", "armor_stand")
+_ENTITY_COLORS = (0xFFB08050, 0xFF9C7A4A, 0xFFC03030, 0xFFD0B090, 0xFF3050C0, 0xFF9C7A4A, 0xFFE0E0E0, 0xFF8A6A3A)
+
+
+def entity_table(js: dict, origin) -> np.ndarray:
+    """[n, 6] float32 rows {kind index, x, y, z (octree coordinates), yaw in radians, actor flag} from the scene JSON."""
+    rows = []
+    for actor, lst in ((0, js.get("entities", [])), (1, js.get("actors", []))):
+        for e in lst:
+            kind = e.get("kind")
+            if kind not in ENTITY_KINDS:
+                continue
+            p = e.get("position", {})
+            x, y, z = (float(p.get(k, 0.0)) - float(o) for k, o in zip("xyz", origin))
+            if "angle" in e:
+                yaw = math.radians(float(e["angle"]))
+            elif "direction" in e and kind == "wallsign":           # 2 north, 3 south, 4 west, 5 east
+                yaw = {2: math.pi, 3: 0.0, 4: math.pi / 2, 5: -math.pi / 2}.get(int(e["direction"]), 0.0)
+            elif "direction" in e:
+                yaw = float(e["direction"]) * math.pi / 8
+            elif "rotation" in e:
+                yaw = float(e["rotation"]) * math.pi / 8
+            elif "pose" in e:
+                allp = e["pose"].get("all") or [0.0, 0.0, 0.0]
+                yaw = float(allp[1]) if len(allp) > 1 else 0.0
+            else:
+                yaw = 0.0
+            rows.append((ENTITY_KINDS.index(kind), x, y, z, yaw, actor))
+    return np.array(rows, np.float32).reshape(-1, 6)
+
+
+def _box_tris(center, half, yaw, material):
+    """12 single-sided triangles (outward faces) of a box rotated by `yaw` about the vertical through its centre."""
+    c, s = math.cos(yaw), math.sin(yaw)
+    corners = []
+    for dx in (-1, 1):
+        for dy in (-1, 1):
+            for dz in (-1, 1):
+                lx, ly, lz = dx * half[0], dy * half[1], dz * half[2]
+                corners.append((center[0] + c * lx + s * lz, center[1] + ly, center[2] - s * lx + c * lz))
+    v = lambda i, j, k: corners[(i << 2) | (j << 1) | k]
+    quads = [((0, 0, 0), (0, 0, 1), (0, 1, 1), (0, 1, 0)), ((1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 0, 1)),   # -x, +x
+             ((0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1)), ((0, 1, 0), (0, 1, 1), (1, 1, 1), (1, 1, 0)),   # -y, +y
+             ((0, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 0)), ((0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1))]   # -z, +z
+    out = []
+    for q in quads:
+        p0, p1, p2, p3 = (v(*k) for k in q)
+        out.append(scenes.pack_triangle(p0, p1, p2, (0, 0), (1, 0), (1, 1), material))
+        out.append(scenes.pack_triangle(p0, p2, p3, (0, 0), (1, 1), (0, 1), material))
+    return out
+
+
+def entity_proxies(table: np.ndarray, materials: List[int]):
+    """(world triangles, actor triangles) as int32 [n, 20]; `materials` = one material pointer per ENTITY_KINDS entry."""
+    world, actors = [], []
+    for kind, x, y, z, yaw, actor in table:
+        k, m = int(kind), materials[int(kind)]
+        name = ENTITY_KINDS[k]
+        dst = actors if actor else world
+        if name == "painting":
+            dst += _box_tris((x, y, z), (0.5, 0.5, 0.03), yaw, m)
+        elif name == "wallsign":
+            dst += _box_tris((x + 0.5, y + 0.55, z + 0.5), (0.5, 0.25, 0.045), yaw, m)
+        elif name == "wall_banner":
+            dst += _box_tris((x + 0.5, y - 0.1, z + 0.5), (0.45, 0.9, 0.04), yaw, m)
+        elif name in ("head", "skull"):
+            dst += _box_tris((x + 0.5, y + 0.25, z + 0.5), (0.25, 0.25, 0.25), yaw, m)
+        elif name == "standing_banner":
+            dst += _box_tris((x + 0.5, y + 0.95, z + 0.5), (0.04, 0.95, 0.04), yaw, m)
+            dst += _box_tris((x + 0.5, y + 1.0, z + 0.5), (0.45, 0.8, 0.03), yaw, m)
+        elif name == "sign":
+            dst += _box_tris((x + 0.5, y + 0.3, z + 0.5), (0.045, 0.3, 0.045), yaw, m)
+            dst += _box_tris((x + 0.5, y + 0.85, z + 0.5), (0.5, 0.25, 0.045), yaw, m)
+        elif name == "armor_stand":
+            dst += _box_tris((x, y + 0.03, z), (0.375, 0.03, 0.375), yaw, m)          # base plate
+            for side in (-0.12, 0.12):                                                 # legs
+                dst += _box_tris((x + side * math.cos(yaw), y + 0.4, z - side * math.sin(yaw)), (0.06, 0.37, 0.06), yaw, m)
+            dst += _box_tris((x, y + 1.05, z), (0.25, 0.28, 0.09), yaw, m)            # body
+            dst += _box_tris((x, y + 1.6, z), (0.2, 0.2, 0.2), yaw, m)                # head
+    arr = lambda lst: np.array(lst, np.int64).astype(np.int32).reshape(-1, 20)
+    return arr(world), arr(actors)
+
+
+def with_entities(sc: scenes.PackedScene, table: np.ndarray) -> scenes.PackedScene:
+    """The scene with the proxies of `table` in its world / actor BVHs (flat-colour materials appended to the palette)."""
+    mats = list(np.asarray(sc.material_palette).tolist())
+    ptrs = []
+    for argb in _ENTITY_COLORS:
+        ptrs.append(len(mats))
+        mats += [0, 0, 0, argb - (1 << 32) if argb >= (1 << 31) else argb, 0, 0]
+    world, actors = entity_proxies(table, ptrs)
+    wn, wtr = scenes.build_bvh(world, 4)
+    if len(actors):
+        an, atr = scenes.build_bvh(actors, 4)
+        an = an.copy().reshape(-1, 7)
+        leaf = an[:, 0] <= 0
+        an[leaf, 0] -= len(wtr)                        # one shared triangle array, as AbstractSceneLoader.java:118-127
+        an, trigs = an.reshape(-1), np.concatenate([wtr, atr])
+    else:
+        an, trigs = scenes.empty_bvh(), wtr
+    import dataclasses
+    return dataclasses.replace(sc, material_palette=np.array(mats, np.int64).astype(np.int32), world_bvh=wn, actor_bvh=an, bvh_trigs=trigs,
+                               name=sc.name + f"+{len(world)}+{len(actors)}tri")
+
+
 FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "benchmark_OpenCL_test.npz")
 REFERENCE_SCENE = "/root/reference/benchmark/OpenCL_test/OpenCL_test"
 
 
-def cached_benchmark_scene(width: int = 1920, height: int = 1080) -> scenes.PackedScene:
+ENTITY_FIXTURE = os.path.join(os.path.dirname(FIXTURE), "benchmark_OpenCL_test_entities.npz")
+
+
+def cached_benchmark_scene(width: int = 1920, height: int = 1080, entities: bool = False) -> scenes.PackedScene:
     """The reference's `benchmark/OpenCL_test` scene (BASELINE.json configs[0]/[1]) as packed arrays.
 
     The committed fixture tests/golden/benchmark_OpenCL_test.npz is this module's conversion of the reference's data
@@ -264,11 +378,18 @@ def cached_benchmark_scene(width: int = 1920, height: int = 1080) -> scenes.Pack
         if not os.path.exists(REFERENCE_SCENE + ".octree2"):
             raise FileNotFoundError("benchmark scene: neither " + REFERENCE_SCENE + ".octree2 nor " + FIXTURE)
         write_fixture()
-    return scenes.load_scene(FIXTURE).with_view(width, height)
+    sc = scenes.load_scene(FIXTURE).with_view(width, height)
+    if entities:  # the scene's 4 188 entities and 389 actors as box proxies in the two BVHs (table fixture: kinds, places, yaws)
+        sc = with_entities(sc, np.load(ENTITY_FIXTURE)["table"])
+    return sc
 
 
 def write_fixture() -> str:
     scenes.save_scene(load_scene(REFERENCE_SCENE + ".octree2", REFERENCE_SCENE + ".json"), FIXTURE, compressed=True)
+    js = json.loads(open(REFERENCE_SCENE + ".json", encoding="latin-1").read())
+    chunks = js.get("chunkList", [])
+    origin = (16.0 * min(c[0] for c in chunks), float(js.get("yMin", 0)), 16.0 * min(c[1] for c in chunks))
+    np.savez_compressed(ENTITY_FIXTURE, table=entity_table(js, origin))
     return FIXTURE
 
 

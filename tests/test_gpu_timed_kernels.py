@@ -124,6 +124,33 @@ def test_city_kernel(gpu_instance, port):
     loader.close()
 
 
+def test_city_with_its_entities(gpu_instance, port):
+    """configs[1] with the scene's own 4 188 entities and 389 actors (box proxies, octree2.with_entities) in the world and
+    actor BVHs: render_pool<18, ., bvh> on the depth-10 octree, whole rows against the oracle; and a close-up view in
+    which the entities fill the picture."""
+    from chunkyclplugin_amd import octree2
+    sc = octree2.cached_benchmark_scene(1920, 1080, entities=True)
+    seeds = native.java_random_ints(16)
+    loader, r = make(gpu_instance, sc)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["bvh"]) == (18, True) and info["pool"] in (16, 32), info
+    compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[::3]), "city + entities")
+    r.close()
+    loader.close()
+    table = np.load(octree2.ENTITY_FIXTURE)["table"]
+    e = table[table[:, 0] == 0][len(table) // 9]              # a painting somewhere in the city
+    near = sc.with_view(320, 200, camera=scenes.look_at_camera((e[1] + 4.0, e[2] + 1.5, e[3] + 3.0), (e[1], e[2], e[3]), 60.0))
+    loader, r = make(gpu_instance, near)
+    r.render_passes(seeds[:6])
+    want = port.render_passes(near, seeds[:6], threads=THREADS)
+    np.testing.assert_array_equal(bits(r.read()), bits(want))
+    bare = octree2.cached_benchmark_scene(320, 200).with_view(320, 200, camera=near.camera)
+    assert not np.array_equal(bits(port.render_passes(bare, seeds[:2], threads=THREADS)), bits(port.render_passes(near, seeds[:2], threads=THREADS)))
+    r.close()
+    loader.close()
+
+
 def test_config0_plumbing_image(gpu_instance, port):
     """BASELINE configs[0] — benchmark/OpenCL_test at 256x256, 16 spp (recorded on the CPU path by tools/config0_cpu.py,
     profiles/r02_config0_cpu.json): the whole image from the HIP path equals the CPU path's, bit for bit."""

@@ -1,6 +1,15 @@
 #!/usr/bin/env python3
-"""Msamples/s of the other BASELINE.json configurations (GPU box): indoor emitter room (configs[3]) and
-entity-heavy world (configs[4], 1 GPU share), each with a parity spot-check against the oracle on a crop."""
+"""Msamples/s of the other BASELINE.json configurations on one MI355X (GPU box), each with a parity spot-check of whole image
+rows against the oracle AT THE TIMED PASS COUNT (the instantiation that is timed is the one that is checked):
+
+  benchmark   configs[1]  the reference's benchmark/OpenCL_test scene (tests/golden/benchmark_OpenCL_test.npz), 1920x1080
+  benchmark_entities      the same with the scene's 4 188 entities + 389 actors as box proxies in the two BVHs
+  indoor      configs[3]  emitter-lit room, sun flag 0, 1920x1080 — as the reference renders it (implicit emitter hits)
+  indoor_nee  configs[3]  the same with CHUNKY_OPT_EMITTER_NEE (the configuration's "NEE on": an extension)
+  entities    configs[4]  32x32-chunk world + 100 000 world / 5 000 actor triangles, 1920x1080 on one GPU
+  entities4k  configs[4]  the same at 3840x2160, rank 0's share of an 8-GPU tile split (what one GPU of the stated config renders)
+
+    python tools/config_bench.py [names...] > profiles/rNN_config_bench.jsonl"""
 import json
 import os
 import sys
@@ -9,16 +18,20 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from chunkyclplugin_amd import native, scenes  # noqa: E402
+from chunkyclplugin_amd import native, parallel, scenes  # noqa: E402
 from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance  # noqa: E402
 from oracle import binding  # noqa: E402
+from oracle.binding import PortExt  # noqa: E402
 
 
-def run(sc, passes=32, launches=3, check_rows=(60, 250, 440, 630, 820, 1010)):
+def run(sc, name, passes=32, launches=3, world=1, ext=None, check_rows=(60, 250, 440, 630, 820, 1010)):
     loader = HipSceneLoader(RendererInstance.get(0))
     loader.load_packed(sc)
     r = HipPathTracingRenderer(loader, sc.width, sc.height)
     r.set_camera(sc.projector_type, sc.camera)
+    r.set_shard(0, world, 256)
+    for k, v in (ext or {}).items():
+        r.set_option({"nee": native.OPT_EMITTER_NEE, "bsdf": native.OPT_BSDF}[k], v)
     seeds = native.java_random_ints(passes * (launches + 1))
     r.render_passes(seeds[:passes])
     r.kernel_time()
@@ -28,22 +41,29 @@ def run(sc, passes=32, launches=3, check_rows=(60, 250, 440, 630, 820, 1010)):
     r.sync()
     dt = time.perf_counter() - t0
     ms, n = r.kernel_time()
-    # parity spot check: 2 passes, three rows
+    info = r.kernel_info()
+    # parity spot check: the timed pass count, whole rows (this rank's pixels of them)
     r.reset()
-    r.render_passes(seeds[:2])
-    got = r.read().reshape(sc.height, sc.width, 3)
-    rows = [min(y, sc.height - 1) for y in check_rows]
+    r.render_passes(seeds[:passes])
+    got = r.read().reshape(-1, 3)
+    rows = [min(y * sc.height // 1080, sc.height - 1) for y in check_rows]
     gids = np.concatenate([np.arange(y * sc.width, (y + 1) * sc.width) for y in rows]).astype(np.int32)
+    gids = np.intersect1d(gids, parallel.owned_gids(sc.width * sc.height, 0, world, 256)).astype(np.int32)
     port = binding.port()
     port.counters(enable=True, reset=True)
     port.counters(reset=True)
-    want = port.render_gids(sc, seeds[:2], gids, threads=os.cpu_count()).reshape(sc.height, sc.width, 3)
+    if ext:
+        with PortExt(port, sc, **ext):
+            want = port.render_gids(sc, seeds[:passes], gids, threads=os.cpu_count()).reshape(-1, 3)
+    else:
+        want = port.render_gids(sc, seeds[:passes], gids, threads=os.cpu_count()).reshape(-1, 3)
     bps = binding.algorithmic_bytes(port.counters(enable=False, reset=True))
-    same = all(np.array_equal(got[y].view(np.uint32), want[y].view(np.uint32)) for y in rows)
-    out = {"scene": sc.name, "size": [sc.width, sc.height], "Msamples/s": sc.width * sc.height * passes * launches / dt / 1e6,
-           "launch_ms": ms / n, "rows_bit_identical_to_oracle": bool(same),
-           "algorithmic_bytes_per_sample": bps}
-    out["algorithmic_GBps"] = bps * sc.width * sc.height * passes / (ms / n * 1e-3) / 1e9
+    same = bool(np.array_equal(got[gids].view(np.uint32), want[gids].view(np.uint32)))
+    n_local = min(parallel.local_slots(sc.width * sc.height, 0, world, 256), sc.width * sc.height)
+    out = {"config": name, "scene": sc.name, "size": [sc.width, sc.height], "share": f"1/{world}", "passes_per_launch": passes,
+           "kernel": info, "Msamples/s": n_local * passes * launches / dt / 1e6, "launch_ms": ms / n,
+           "rows_bit_identical_to_oracle": same, "pixels_checked": int(gids.size), "algorithmic_bytes_per_sample": bps}
+    out["algorithmic_GBps"] = bps * n_local * passes / (ms / n * 1e-3) / 1e9
     out["frac_of_8TBps"] = out["algorithmic_GBps"] / 8000.0
     r.close()
     loader.close()
@@ -51,19 +71,26 @@ def run(sc, passes=32, launches=3, check_rows=(60, 250, 440, 630, 820, 1010)):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["benchmark", "indoor", "entities"]
+    which = sys.argv[1:] or ["benchmark", "benchmark_entities", "indoor", "indoor_nee", "entities", "entities4k"]
     res = []
-    if "benchmark" in which:  # BASELINE configs[1]: the reference's own benchmark scene, 1920x1080
+    if "benchmark" in which:
         from chunkyclplugin_amd import octree2
-        res.append(run(octree2.cached_benchmark_scene(1920, 1080), passes=64, launches=3))
+        res.append(run(octree2.cached_benchmark_scene(1920, 1080), "configs[1]", passes=64, launches=3))
+    if "benchmark_entities" in which:
+        from chunkyclplugin_amd import octree2
+        res.append(run(octree2.cached_benchmark_scene(1920, 1080, entities=True), "configs[1] + the scene's entities (box proxies)",
+                       passes=32, launches=2))
     if "indoor" in which:
-        res.append(run(scenes.indoor_room(size=64, width=1920, img_height=1080)))
-    if "entities" in which:
+        res.append(run(scenes.indoor_room(size=64, width=1920, img_height=1080), "configs[3] (reference light transport)", passes=32))
+    if "indoor_nee" in which:
+        res.append(run(scenes.indoor_room(size=64, width=1920, img_height=1080), "configs[3] with emitter NEE (extension)", passes=32,
+                       ext={"nee": 1}))
+    if "entities" in which or "entities4k" in which:
         base = scenes.cached_outdoor_world(chunks=32, height=256)
-        t0 = time.time()
-        sc = scenes.add_entities(base, 100000, seed=11, actor_tris=5000,
-                                 region=((40, 90, 40), (470, 170, 470)))
-        print("entities built in %.1fs" % (time.time() - t0), file=sys.stderr)
-        res.append(run(sc, passes=16, launches=2))
+        sc = scenes.add_entities(base, 100000, seed=11, actor_tris=5000, region=((40, 90, 40), (470, 170, 470)))
+        if "entities" in which:
+            res.append(run(sc, "configs[4] at 1920x1080 on one GPU", passes=16, launches=2))
+        if "entities4k" in which:
+            res.append(run(sc.with_view(3840, 2160), "configs[4] at 3840x2160, rank 0 of 8", passes=16, launches=2, world=8))
     for x in res:
-        print(json.dumps(x))
+        print(json.dumps(x), flush=True)

@@ -25,7 +25,13 @@ G[td]="TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum GRBM_GUI_ACTIVE"
 G[fetch]="FETCH_SIZE"
 G[write]="WRITE_SIZE"
 for g in ${PMC_GROUPS:-sq1 sq2 tcc tcp fetch write}; do
-  timeout 600 rocprofv3 --pmc ${G[$g]} --output-format csv -d $OUT/$g -- python3 $R/bench.py --no-cpu --no-roofline --steps 2 --warmup 1 "$@" > $OUT/$g.log 2>&1 || echo "group $g failed"
+  # PMC_SCRIPT=<python file + args> profiles that instead of the bench (e.g. "tools/config_bench.py entities"); the program
+  # after -- is python3 itself (never env / bash -c: the profiler's library initialises the GPU before the program starts)
+  if [ -n "${PMC_SCRIPT:-}" ]; then
+    (cd $R && timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc ${G[$g]} --output-format csv -d $OUT/$g -- python3 $PMC_SCRIPT > $OUT/$g.log 2>&1) || echo "group $g failed"
+  else
+    timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc ${G[$g]} --output-format csv -d $OUT/$g -- python3 $R/bench.py --no-cpu --no-roofline --steps 2 --warmup 1 "$@" > $OUT/$g.log 2>&1 || echo "group $g failed"
+  fi
 done
-python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.json
+python3 $R/tools/pmc_summary.py $OUT ${PMC_KERNEL:-render} > $OUT/summary.json
 cat $OUT/summary.json
