@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -230,6 +231,14 @@ extern "C" int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree,
     scene->wide_meta = WideTree();
     int bits[kWideMaxLevels];
     int nlev = default_wide_levels(depth, bits);
+    if (const char* e = getenv("CHUNKY_DEBUG_WIDE_BITS")) {  // experiments: another split, e.g. "4,3,2" (16^3 top node)
+        nlev = 0;
+        for (const char* q = e; *q && nlev < kWideMaxLevels;) {
+            bits[nlev++] = atoi(q);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+    }
     const char* why = "";
     WideTree wt;
     if (build_wide_tree(tree, n, depth, bits, nlev, &wt, &why)) {

@@ -26,6 +26,13 @@ struct LdsStack {
     DEV int pop(int slot) { return base[slot * stride]; }
 };
 
+#ifndef CHUNKY_LDS_TOP
+#define CHUNKY_LDS_TOP 0
+#endif
+#if CHUNKY_LDS_TOP
+// experiment: render_pool<-1, 32> copies the top node (at most 16^3 entries) behind its pool area in dynamic LDS
+constexpr int chunky_lds_top_offset = 4 * (32 * 128 + 32 * 8) / 4;
+#endif
 // Leaf lookup of K/octree.h:81-89: cell (bx,by,bz) -> block pointer `data` and leaf `level`.
 // TREE = 0 walks the reference layout from the root, one bit per level; TREE = -1 walks the wide
 // re-layout (widetree.hpp) with per-level bit counts from the scene view; TREE = 16 + n walks the
@@ -88,6 +95,13 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
                 const int sh = S.wide_shift[i], b = S.wide_bits[i];
                 const unsigned ix = __builtin_amdgcn_ubfe((unsigned)bx, sh, b), iy = __builtin_amdgcn_ubfe((unsigned)by, sh, b),
                                iz = __builtin_amdgcn_ubfe((unsigned)bz, sh, b);
+#if CHUNKY_LDS_TOP  // experiment (profiles/r02_lds_top_experiment.json): the top node staged in LDS by render_pool
+                if (i == 0 && TREE == -1) {
+                    extern __shared__ int lds_all[];
+                    e = lds_all[chunky_lds_top_offset + ((((ix << b) | iy) << b) | iz)];
+                    continue;
+                }
+#endif
                 e = (int)tree[(unsigned)e + ((((ix << b) | iy) << b) | iz)];  // unsigned: 32-bit offset off an SGPR base
             }
         }
@@ -224,17 +238,21 @@ DEV int shard_gid(const ShardView& T, int local) {
 // render_pool's pixel slots: with one rank a tile of 256 slots is a 16 x 16 block of pixels (neighbouring paths meet the same
 // part of the scene: L1 / L2 hits); with several ranks a tile is one of the rank's runs of consecutive pixel indices
 // (chunky_render_set_shard).  Returns width * height for a padding slot.
+#ifndef CHUNKY_TILE_LOG
+#define CHUNKY_TILE_LOG 4  // tiles of 16 x 16 pixels
+#endif
+constexpr int kTileLog = CHUNKY_TILE_LOG, kTileEdge = 1 << kTileLog, kSampleTile = kTileEdge * kTileEdge;  // pixel slots per tile
 DEV int pool_slot_gid(const ShardView& T, int width, int height, int slot) {
     if (T.world != 1) return slot < T.n_local ? shard_gid(T, slot) : width * height;
-    const int bw = (width + 15) >> 4;
-    const int b = slot >> 8, i = slot & 255;
+    const int bw = (width + kTileEdge - 1) >> kTileLog;
+    const int b = slot >> (2 * kTileLog), i = slot & (kSampleTile - 1);
     const int by = b / bw, bx = b - by * bw;
-    const int x = (bx << 4) | (i & 15), y = (by << 4) | (i >> 4);
+    const int x = (bx << kTileLog) | (i & (kTileEdge - 1)), y = (by << kTileLog) | (i >> kTileLog);
     return (x < width && y < height) ? y * width + x : width * height;
 }
 __host__ __device__ inline long long pool_tiles(const ShardView& T, int width, int height) {
-    if (T.world != 1) return ((long long)T.n_local + 255) / 256;
-    return (long long)((width + 15) >> 4) * ((height + 15) >> 4);
+    if (T.world != 1) return ((long long)T.n_local + kSampleTile - 1) / kSampleTile;
+    return (long long)((width + kTileEdge - 1) >> kTileLog) * ((height + kTileEdge - 1) >> kTileLog);
 }
 
 template <int TREE>
@@ -1548,7 +1566,6 @@ constexpr int kPoolPark = CHUNKY_POOL_PARK;
 constexpr int kModelBatch = CHUNKY_MODEL_BATCH;  // model-block candidates that share one execution of their phase
 constexpr int kPoolRefill = CHUNKY_POOL_REFILL;  // leave the march loop to refill once this many lanes are free and parked marchers exist
 constexpr int kSampleBatch = 256;                // sample indices a wave claims per atomic
-constexpr int kSampleTile = 256;                 // pixel slots per tile of the sample order (a power of two)
 
 // stats (STATS = true), same layout as render_waves: [0..8] executions / lanes / cycles of MARCH, BLOCK (and the entity-BVH
 // walk), SHADE; [9..11] wave lifetimes; [12] swap rounds, [13] paths swapped; [14..] parts of SHADE.
@@ -1587,6 +1604,14 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         stacks.base = (int*)(base + K * 16 * WORDS + K * 8);
         if (BVH && lane < K) P.park[lane] = make_uint4(0u, 0u, (unsigned)(64 + lane) << 16, 0u);  // the parked slots' stack ids
     }
+#if CHUNKY_LDS_TOP
+    if (TREE == -1 && K == 32 && !BVH && !EXT) {
+        const SceneView S0 = arg_copy(&fresh_args()->S);
+        const int n_top = 1 << (3 * S0.wide_bits[0]);
+        for (int i = (int)threadIdx.x; i < n_top && i < 4096; i += 256) lds[chunky_lds_top_offset + i] = (int)S0.wide[i];
+        __syncthreads();
+    }
+#endif
     LdsStack stack{lds, 0};  // render_waves' per-lane stacks are not used here
     LaneState L;
     L.h.material = 0;
@@ -2148,7 +2173,10 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
             default: tree = -1; k = render_pool<-1, kPoolPark, false>; break;
         }
     }
-    const size_t lds = (size_t)(block / 64) * (size_t)(park * 16 * words + park * 8 + (64 + park) * depth * 4);
+    size_t lds = (size_t)(block / 64) * (size_t)(park * 16 * words + park * 8 + (64 + park) * depth * 4);
+#if CHUNKY_LDS_TOP
+    if (tree == -1 && park == 32 && !bvh && !ext) lds += 4096 * 4;
+#endif
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
     if (e != hipSuccess) return e;
