@@ -121,7 +121,10 @@ int chunky_render_set_option(chunky_render* r, int option, int32_t value);
  * ranks (one RCCL collective per read-back) reproduces the 1-GPU image bit for bit. */
 int chunky_render_set_shard(chunky_render* r, int rank, int world, int tile);
 /* Use a caller-owned device buffer (3*width*height floats) as the framebuffer, e.g. a torch tensor
- * that torch.distributed reduces over RCCL.  NULL returns to the internal buffer. */
+ * that torch.distributed reduces over RCCL.  NULL returns to the internal buffer.
+ * Ordering contract: the library runs on its own non-blocking stream and only synchronises THAT stream here.  The caller
+ * must have completed every write of its own to the buffer (e.g. torch.zeros: torch.cuda.synchronize() first) before the
+ * next chunky_render_passes, and must call chunky_render_sync before it reads or reduces the buffer on another stream. */
 int chunky_render_set_device_buffer(chunky_render* r, void* device_ptr);
 int chunky_render_device_buffer(chunky_render* r, void** device_ptr);
 /* Zero the device framebuffer (the reference uploads a zeroed passBuffer, OpenClPathTracingRenderer.java:61,71). */
