@@ -48,6 +48,7 @@ struct chunky_ctx {
     hipStream_t stream = nullptr;
     std::recursive_mutex mu;  // the reference's renderLock
     std::string name;
+    void* gamma_table = nullptr;  // 256 floats: the byte thresholds of the GAMMA / ACES tone maps (gamma_thresholds)
 };
 
 struct DevBuf {
@@ -176,6 +177,7 @@ extern "C" int chunky_shutdown(chunky_ctx* ctx) {
         std::lock_guard<std::recursive_mutex> g(ctx->mu);
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->gamma_table) (void)hipFree(ctx->gamma_table);
         (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -1203,6 +1205,47 @@ extern "C" int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int d
 }
 
 // ------------------------------------------------------------------------------------ tone map
+// The last steps of the GAMMA and ACES curves for one channel value (post_processing_filter.cl:24-27, rgba.h:9-14) on the
+// host, with the rt_pow the kernels and the checkers share: pow(c, 1/2.2) * 255 + 0.5 -> (uint), saturating -> min(255).
+static unsigned gamma_byte_host(float c) {
+    const float f = rt_pow(c, (float)(1.0 / 2.2)) * 255.0f + 0.5f;
+    const unsigned u = !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (unsigned)f);
+    return u > 255u ? 255u : u;
+}
+// T[k] (k = 1..255) = the smallest non-negative float whose byte is >= k, by bisection over the float's bit pattern (the
+// byte is a non-decreasing function of c: checked over every float by tests/test_filter.py); T[0] = 0.
+static const float* gamma_thresholds() {
+    static float T[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        T[0] = 0.0f;
+        for (int k = 1; k < 256; k++) {
+            uint32_t lo = 0u, hi = 0x7F800000u;  // byte(+0) = 0 < k <= byte(+inf) = 255
+            while (hi - lo > 1u) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                float c;
+                memcpy(&c, &mid, 4);
+                if (gamma_byte_host(c) >= (unsigned)k) hi = mid; else lo = mid;
+            }
+            memcpy(&T[k], &hi, 4);
+        }
+    });
+    return T;
+}
+extern "C" int chunky_filter_gamma_thresholds(float* out256) {
+    if (!out256) return fail(CHUNKY_E_INVALID, "gamma_thresholds: NULL output");
+    memcpy(out256, gamma_thresholds(), 256 * sizeof(float));
+    return CHUNKY_OK;
+}
+static int device_gamma_table(chunky_ctx* ctx, const float** out) {
+    if (!ctx->gamma_table) {
+        HIP_TRY(hipMalloc(&ctx->gamma_table, 256 * sizeof(float)));
+        HIP_TRY(hipMemcpy(ctx->gamma_table, gamma_thresholds(), 256 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *out = (const float*)ctx->gamma_table;
+    return CHUNKY_OK;
+}
+
 extern "C" int chunky_filter_frame(chunky_ctx* ctx, int width, int height, double exposure, const double* input,
                                    int32_t* argb_out, int type) {
     if (!ctx) return fail(CHUNKY_E_INVALID, "filter_frame: NULL context");
@@ -1216,7 +1259,9 @@ extern "C" int chunky_filter_frame(chunky_ctx* ctx, int width, int height, doubl
     HIP_TRY(in.upload(input, (size_t)n * 24, ctx->stream));
     HIP_TRY(hipMalloc(&out.p, (size_t)n * 4));
     out.bytes = (size_t)n * 4;
-    HIP_TRY(launch_filter(n, (float)exposure, (const double*)in.p, (unsigned*)out.p, type, ctx->stream));
+    const float* table = nullptr;
+    if (int rc = device_gamma_table(ctx, &table)) return rc;
+    HIP_TRY(launch_filter(n, (float)exposure, (const double*)in.p, (unsigned*)out.p, type, ctx->stream, table));
     HIP_TRY(hipMemcpyAsync(argb_out, out.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return CHUNKY_OK;
@@ -1231,12 +1276,14 @@ extern "C" int chunky_filter_frame_device(chunky_ctx* ctx, int64_t n_pixels, flo
         return fail(CHUNKY_E_INVALID, "filter_frame_device: misaligned buffer");
     std::lock_guard<std::recursive_mutex> guard(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
+    const float* table = nullptr;
+    if (int rc = device_gamma_table(ctx, &table)) return rc;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     hipError_t err = hipEventRecord(e0, ctx->stream);
     for (int k = 0; k < repeat && err == hipSuccess; k++)
-        err = launch_filter(n_pixels, exposure, (const double*)d_input, (unsigned*)d_argb, type, ctx->stream);
+        err = launch_filter(n_pixels, exposure, (const double*)d_input, (unsigned*)d_argb, type, ctx->stream, table);
     if (err == hipSuccess) err = hipEventRecord(e1, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
     float ms = 0;

@@ -2022,6 +2022,25 @@ DEV unsigned filter_pack(float r, float g, float b) {
     return 0xFF000000u | (ur << 16) | (ug << 8) | ub;  // alpha: (uint)(1 * 255 + 0.5) = 255
 }
 
+// GAMMA and ACES end in pow(c, 1/2.2) -> c * 255 + 0.5 -> (uint) -> clamp to 255 (post_processing_filter.cl:24-27,33-38,
+// rgba.h:9-14): a monotone step function of the float c with at most 255 steps.  Its thresholds (kT[k] = the smallest float
+// whose byte is >= k, found on the host by bisection with the same rt_pow: capi.hip gamma_thresholds; monotonicity is checked
+// exhaustively by tests/test_filter.py) replace the six binary64 rt_pow per lane that made these two curves issue-bound:
+// a hardware log2 / exp2 estimate of the byte, then two rounds of "is c on the right side of the neighbouring thresholds".
+// Same byte for every float: NaN and negative values fail every comparison (byte 0, as rt_pow's NaN does), except -inf, whose
+// power is +inf (C99 pow(-inf, y > 0)).
+DEV unsigned gamma_byte(float c, const float* __restrict__ kT) {
+    const float est = __builtin_amdgcn_exp2f((float)(1.0 / 2.2) * __builtin_amdgcn_logf(c)) * 255.0f + 0.5f;
+    int k = est >= 255.0f ? 255 : (est > 0.0f ? (int)est : 0);  // NaN -> 0
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        const bool up = k < 255 && c >= kT[k < 255 ? k + 1 : 255];
+        const bool down = k > 0 && !(c >= kT[k]);
+        k += (int)up - (int)down;
+    }
+    return c == -rt_inf() ? 255u : (unsigned)k;
+}
+
 // The curve of K's switch (post_processing_filter.cl:23-45) applied to the N channel values of a lane at once: the
 // switch is taken once, and inside a case the N evaluations are independent instruction streams in one basic
 // block, so the long dependent chain of each rt_pow overlaps with the others'.
@@ -2052,9 +2071,12 @@ DEV void filter_curve(float (&c)[N], float exposure, int type) {
 }
 
 __global__ __launch_bounds__(256) void filter_kernel(long long n, float exposure, const double* __restrict__ in,
-                                                     unsigned* __restrict__ out, int type, int vec_ok) {
+                                                     unsigned* __restrict__ out, int type, int vec_ok, const float* __restrict__ thresholds) {
     __shared__ float stage[3 * kFilterTile];
+    __shared__ float kT[256];
     const int t = threadIdx.x;
+    const bool bytes = thresholds != nullptr && (type == 0 || type == 2);  // GAMMA, ACES through the threshold table
+    if (bytes) kT[t] = thresholds[t];
     const long long total = 3 * n;
     for (long long base = (long long)blockIdx.x * kFilterTile; base < n; base += (long long)gridDim.x * kFilterTile) {
         const long long first = 3 * base;
@@ -2077,11 +2099,25 @@ __global__ __launch_bounds__(256) void filter_kernel(long long n, float exposure
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) c[3 * k + ch] = stage[3 * px + ch];
         }
-        filter_curve<6>(c, exposure, type);
+        if (bytes) {
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int px = t + 256 * k;
-            if (base + px < n) out[base + px] = filter_pack(c[3 * k], c[3 * k + 1], c[3 * k + 2]);
+            for (int i = 0; i < 6; i++) {
+                c[i] *= exposure;
+                if (type == 2) c[i] = filter_aces(c[i]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int px = t + 256 * k;
+                if (base + px < n)
+                    out[base + px] = 0xFF000000u | (gamma_byte(c[3 * k], kT) << 16) | (gamma_byte(c[3 * k + 1], kT) << 8) | gamma_byte(c[3 * k + 2], kT);
+            }
+        } else {
+            filter_curve<6>(c, exposure, type);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int px = t + 256 * k;
+                if (base + px < n) out[base + px] = filter_pack(c[3 * k], c[3 * k + 1], c[3 * k + 2]);
+            }
         }
         __syncthreads();
     }
@@ -2347,12 +2383,13 @@ hipError_t launch_math_selftest(int which, int n, const float* a, const float* b
     return hipGetLastError();
 }
 
-hipError_t launch_filter(long long n_pixels, float exposure, const double* in, unsigned* out, int type, hipStream_t stream) {
+hipError_t launch_filter(long long n_pixels, float exposure, const double* in, unsigned* out, int type, hipStream_t stream,
+                         const float* thresholds) {
     if (n_pixels <= 0) return hipSuccess;
     long long tiles = (n_pixels + kFilterTile - 1) / kFilterTile;
     int blocks = (int)(tiles < 4096 ? tiles : 4096);
     int vec_ok = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
-    hipLaunchKernelGGL(filter_kernel, dim3(blocks), dim3(256), 0, stream, n_pixels, exposure, in, out, type, vec_ok);
+    hipLaunchKernelGGL(filter_kernel, dim3(blocks), dim3(256), 0, stream, n_pixels, exposure, in, out, type, vec_ok, thresholds);
     return hipGetLastError();
 }
 

@@ -63,7 +63,9 @@ hipError_t launch_trace_records(int variant, const SceneView& S, const CameraVie
                                 hipStream_t stream);
 hipError_t launch_preview(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int* argb,
                           hipStream_t stream);
-hipError_t launch_filter(long long n_pixels, float exposure, const double* in, unsigned* out, int type, hipStream_t stream);
+// thresholds: 256 floats on the device (capi.hip gamma_thresholds) or null = evaluate pow per channel
+hipError_t launch_filter(long long n_pixels, float exposure, const double* in, unsigned* out, int type, hipStream_t stream,
+                         const float* thresholds = nullptr);
 hipError_t launch_math_selftest(int which, int n, const float* a, const float* b, float* out, hipStream_t stream);
 
 }  // namespace chunky

@@ -128,6 +128,7 @@ def lib() -> C.CDLL:
             "chunky_java_random_ints": [i64, vp, C.c_int],
             "chunky_selftest_math": [vp, C.c_int, C.c_int, vp, vp, vp],
             "chunky_filter_frame": [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_int],
+            "chunky_filter_gamma_thresholds": [vp],
             "chunky_filter_frame_device": [vp, i64, f32, vp, vp, C.c_int, C.c_int, C.POINTER(f32)],
             "chunky_widetree_lookup": [vp, i64, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.POINTER(i64)],
         }

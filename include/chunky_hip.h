@@ -229,6 +229,11 @@ int chunky_java_random_ints(int64_t seed, int32_t* out, int n);
 #define CHUNKY_FILTER_HABLE 3
 int chunky_filter_frame(chunky_ctx* ctx, int width, int height, double exposure, const double* input,
                         int32_t* argb_out, int type);
+/* Host-side instrument (no device needed): the 256 thresholds the GAMMA / ACES curves are evaluated with — T[k] = the smallest
+ * float c >= 0 whose output byte min(255, (uint)(pow(c, 1/2.2) * 255 + 0.5)) is >= k (post_processing_filter.cl:24-27,
+ * rgba.h:9-14).  The byte is a monotone step function of c, so comparing c with these is the same function as evaluating
+ * pow; tests/test_filter.py checks that over every float. */
+int chunky_filter_gamma_thresholds(float* out256);
 /* Same kernel on buffers already in device memory (`d_input`: 3*n_pixels doubles, `d_argb`: n_pixels words),
  * enqueued `repeat` times on the context's stream and waited for; *kernel_ms (may be NULL) receives the mean
  * device time of one launch from HIP events on that stream. */

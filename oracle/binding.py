@@ -274,6 +274,14 @@ class PortLib(_Lib):
         self.lib.port_sample_linear(len(st), _ptr(st), _ptr(rgba), rgba.shape[1], rgba.shape[0], _ptr(out))
         return out
 
+    def gamma_scan(self, lo_bits: int, hi_bits: int, thresholds, threads: int = 8) -> int:
+        """Bit patterns in [lo, hi] whose GAMMA byte breaks monotonicity or disagrees with the threshold table."""
+        t = np.ascontiguousarray(thresholds, np.float32)
+        assert t.size == 256
+        self.lib.port_gamma_scan.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
+        self.lib.port_gamma_scan.restype = C.c_int64
+        return int(self.lib.port_gamma_scan(lo_bits, hi_bits, _ptr(t), threads))
+
     def counters(self, enable: Optional[bool] = None, reset: bool = False) -> dict:
         if enable is not None:
             self.lib.port_counters_enable(1 if enable else 0)

@@ -1055,6 +1055,47 @@ void port_sample_linear(int n, const float* st, const uint8_t* rgba, int w, int 
     }
 }
 
+/* Exhaustive check behind the threshold table of the HIP tone-map kernel: over every float with bit pattern in [lo, hi] the
+ * output byte of the GAMMA tail — min(255, (uint)(pow(c, 1/2.2) * 255 + 0.5)), post_processing_filter.cl:24-27, rgba.h:9-14 —
+ * never decreases as c grows, and changes exactly at `thresholds[k]` (the smallest float whose byte is >= k).  Returns the
+ * number of bit patterns that break either. */
+static unsigned gamma_byte_of(float c) {
+    const float f = rt_pow(c, (float)(1.0 / 2.2)) * 255.0f + 0.5f;
+    const unsigned u = !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (unsigned)f);
+    return u > 255u ? 255u : u;
+}
+int64_t port_gamma_scan(uint32_t lo, uint32_t hi, const float* thresholds, int threads) {
+    int64_t bad = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(+ : bad)
+    for (int64_t chunk = lo >> 16; chunk <= (int64_t)(hi >> 16); chunk++) {
+        uint32_t b0 = (uint32_t)chunk << 16, b1 = b0 | 0xFFFFu;
+        if (b0 < lo) b0 = lo;
+        if (b1 > hi) b1 = hi;
+        float c;
+        uint32_t prev_bits = b0 ? b0 - 1 : 0;
+        memcpy(&c, &prev_bits, 4);
+        unsigned prev = gamma_byte_of(c);
+        for (uint64_t b = b0; b <= b1; b++) {
+            const uint32_t bits = (uint32_t)b;
+            memcpy(&c, &bits, 4);
+            const unsigned k = gamma_byte_of(c);
+            unsigned by_table = 0; /* number of thresholds T[1..255] <= c, by bisection */
+            {
+                int a = 0, z = 255; /* T[a] <= c < T[z + 1] */
+                while (a < z) {
+                    const int m = (a + z + 1) >> 1;
+                    if (c >= thresholds[m]) a = m; else z = m - 1;
+                }
+                by_table = (unsigned)a;
+            }
+            if (k < prev || k != by_table) bad++;
+            prev = k;
+        }
+    }
+    return bad;
+}
+
 /* ------------------------------------------------------------------------------ tone map ----
  * `filter`, tonemap/include/post_processing_filter.cl:5-51, with fp64 present (double.h:19-21):
  * per channel c = (float)input * exposure, then the curve selected by `type`, then color_to_argb

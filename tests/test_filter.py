@@ -98,7 +98,49 @@ def test_pow_accuracy_and_specials(port):
     assert np.isnan(port.pow(np.array([-1.0, nan, 2.0], np.float32), np.array([0.5, 1.0, nan], np.float32))).all()
 
 
+def test_gamma_thresholds_are_the_gamma_curve(port):
+    """The HIP kernel evaluates the GAMMA and ACES curves' last steps — pow(c, 1/2.2) * 255 + 0.5 -> (uint) -> min 255 — by
+    comparing c with 255 thresholds instead of evaluating pow.  That is the same function iff the byte never decreases with
+    c and steps exactly at the thresholds: checked here for EVERY float from 0 to 1.125 (1.07e9 bit patterns, the C
+    restatement's rt_pow), and above on a sample up to +inf; NaN and negative values give byte 0 either way."""
+    import os
+    from chunkyclplugin_amd import native
+    T = np.zeros(256, np.float32)
+    native.check(native.lib().chunky_filter_gamma_thresholds(T.ctypes.data))
+    assert T[0] == 0 and (np.diff(T[1:]) > 0).all() and 0.99 < T[255] < 1.0
+    assert port.gamma_scan(0, 0x3F900000, T, threads=os.cpu_count() or 8) == 0
+    for lo in range(0x3F900000, 0x7F800000, 0x01000000):            # the rest of the positive floats, 65 536 at a time
+        assert port.gamma_scan(lo, lo + 0xFFFF, T, threads=2) == 0
+    assert port.gamma_scan(0x7F7F0000, 0x7F800000, T, threads=2) == 0   # up to +inf
+    # NaN, negative, -0: pow gives NaN / NaN / +0 -> byte 0, and every comparison with a threshold fails for them too;
+    # -inf is the exception on both sides: pow(-inf, 1/2.2) = +inf (C99) -> byte 255
+    x = np.array([np.nan, -1.0, -0.0, -1e-30, -np.inf], np.float64)
+    words = port.filter(np.repeat(x, 3), 1.0, 0)
+    assert (words[:4] == 0xFF000000).all() and words[4] == 0xFFFFFFFF
+
+
 # ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_gamma_thresholds_edge_values(gpu_instance, port):
+    """GAMMA and ACES on the device at, just below and just above every threshold, and on special values: the words of the
+    C restatement (which evaluates pow)."""
+    from chunkyclplugin_amd import native
+    T = np.zeros(256, np.float32)
+    native.check(native.lib().chunky_filter_gamma_thresholds(T.ctypes.data))
+    bits = T[1:].view(np.uint32).astype(np.int64)
+    near = np.concatenate([bits + d for d in (-2, -1, 0, 1, 2)]).astype(np.uint32).view(np.float32)
+    rng = np.random.default_rng(12)
+    x = np.concatenate([near, [0.0, -0.0, np.inf, -np.inf, np.nan, -1.0, 1.0, 0.5, 1e-45, 1e-38, 3e38, 2.0],
+                        rng.uniform(0, 1.2, 30000), 10.0 ** rng.uniform(-45, 5, 5000)]).astype(np.float64)
+    x = np.concatenate([x, np.zeros((-x.size) % 3)])
+    n = x.size // 3
+    for t in (0, 2):
+        for e in (1.0, 0.73, 2.5):
+            out = np.zeros(n, np.uint32)
+            native.check(native.lib().chunky_filter_frame(gpu_instance._h, n, 1, e, native.ptr(x), native.ptr(out), t))
+            np.testing.assert_array_equal(out, port.filter(x, e, t), err_msg=f"type {t} exposure {e}")
+
+
 @pytest.mark.gpu
 def test_gpu_filter_matches_reference_goldens(gpu_instance):
     from chunkyclplugin_amd.renderer import HipPostProcessingFilter
