@@ -1344,43 +1344,54 @@ DEV int phase_class(int st) {
     return st == ST_MARCH ? 0 : (st == ST_BLOCK ? 1 : (st == ST_DONE ? 3 : (st == ST_MODEL ? 4 : ((st == ST_BVH || st == ST_LEAF) ? 5 : 2))));
 }
 
+// A parked path is WORDS 16-byte words.  7 words without entity BVHs (the march-step count shares word 0 with the flags —
+// launch_pool sends draw depths above 65535 to render_waves — and the candidate block takes the place of the BVH cursor's
+// word); 8 with them; 9 for the extended integrator.  The flag bits sit where LaneState's bit-fields have them.
 template <int WORDS>
 DEV void pool_pack(const LaneState& L, uint4 (&v)[WORDS]) {
-    const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.cand_level << 10) |
-                          ((unsigned)L.trace_hit << 14) | ((unsigned)L.bvh_which << 15) | ((unsigned)L.pid << 16) |
-                          ((unsigned)L.tkind << 24) | ((unsigned)L.after_nee << 26);
+    constexpr int H = WORDS == 7 ? 5 : 6;  // first of the two words of the main record
+    const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.trace_hit << 10) |
+                          ((unsigned)L.cand_level << 11) | ((unsigned)L.bvh_which << 15) |
+                          (WORDS == 7 ? (unsigned)L.steps << 16 : ((unsigned)L.pid << 16) | ((unsigned)L.tkind << 24) | ((unsigned)L.after_nee << 26));
     if (WORDS > 8) v[WORDS - 1] = make_uint4(__float_as_uint(L.pend.x), __float_as_uint(L.pend.y), __float_as_uint(L.pend.z), (unsigned)L.h.spec);
-    v[0] = make_uint4((unsigned)L.sidx, L.rng, misc, (unsigned)L.steps);
+    v[0] = make_uint4((unsigned)L.sidx, L.rng, misc, WORDS == 7 ? (unsigned)L.cand_data : (unsigned)L.steps);
     v[1] = make_uint4(__float_as_uint(L.radiance.x), __float_as_uint(L.radiance.y), __float_as_uint(L.radiance.z), __float_as_uint(L.throughput.x));
     v[2] = make_uint4(__float_as_uint(L.throughput.y), __float_as_uint(L.throughput.z), __float_as_uint(L.o.x), __float_as_uint(L.o.y));
     v[3] = make_uint4(__float_as_uint(L.o.z), __float_as_uint(L.d.x), __float_as_uint(L.d.y), __float_as_uint(L.d.z));
     v[4] = make_uint4(__float_as_uint(L.inv.x), __float_as_uint(L.inv.y), __float_as_uint(L.inv.z), __float_as_uint(L.dist_march));
-    v[5] = make_uint4((unsigned)L.bvh_cur, (unsigned)L.bvh_top, __float_as_uint(L.bvh_dist), (unsigned)L.cand_data);  // dead words without entity BVHs
-    v[6] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
-    v[7] = make_uint4(__float_as_uint(L.h.color.x), __float_as_uint(L.h.color.y), __float_as_uint(L.h.color.z), __float_as_uint(L.h.emittance));
+    if (WORDS > 7) v[5] = make_uint4((unsigned)L.bvh_cur, (unsigned)L.bvh_top, __float_as_uint(L.bvh_dist), (unsigned)L.cand_data);
+    v[H] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
+    v[H + 1] = make_uint4(__float_as_uint(L.h.color.x), __float_as_uint(L.h.color.y), __float_as_uint(L.h.color.z), __float_as_uint(L.h.emittance));
 }
 template <int WORDS>
 DEV void pool_unpack(LaneState& L, const uint4 (&v)[WORDS]) {
+    constexpr int H = WORDS == 7 ? 5 : 6;
     if (WORDS > 8) {
         L.pend = mk3(__uint_as_float(v[WORDS - 1].x), __uint_as_float(v[WORDS - 1].y), __uint_as_float(v[WORDS - 1].z));
         L.h.spec = (int)v[WORDS - 1].w;
     }
-    L.tkind = (v[0].z >> 24) & 3u; L.after_nee = (v[0].z >> 26) & 1u;
-    L.sidx = (int)v[0].x; L.rng = v[0].y; L.steps = (int)v[0].w;
-    L.depth = v[0].z & 0xFFu; L.shadow = (v[0].z >> 8) & 1u; L.oct_hit = (v[0].z >> 9) & 1u; L.cand_level = (v[0].z >> 10) & 15u;
-    L.trace_hit = (v[0].z >> 14) & 1u; L.bvh_which = (v[0].z >> 15) & 1u; L.pid = (int)((v[0].z >> 16) & 0xFFu);
-    L.bvh_cur = (int)v[5].x; L.bvh_top = (int)v[5].y; L.bvh_dist = __uint_as_float(v[5].z);
+    L.sidx = (int)v[0].x; L.rng = v[0].y;
+    L.depth = v[0].z & 0xFFu; L.shadow = (v[0].z >> 8) & 1u; L.oct_hit = (v[0].z >> 9) & 1u; L.trace_hit = (v[0].z >> 10) & 1u;
+    L.cand_level = (v[0].z >> 11) & 15u; L.bvh_which = (v[0].z >> 15) & 1u;
+    if (WORDS == 7) {
+        L.steps = (int)(v[0].z >> 16);
+        L.cand_data = (int)v[0].w;
+    } else {
+        L.pid = (int)((v[0].z >> 16) & 0xFFu); L.tkind = (v[0].z >> 24) & 3u; L.after_nee = (v[0].z >> 26) & 1u;
+        L.steps = (int)v[0].w;
+        L.bvh_cur = (int)v[5].x; L.bvh_top = (int)v[5].y; L.bvh_dist = __uint_as_float(v[5].z);
+        L.cand_data = (int)v[5].w;
+    }
     L.radiance = mk3(__uint_as_float(v[1].x), __uint_as_float(v[1].y), __uint_as_float(v[1].z));
     L.throughput = mk3(__uint_as_float(v[1].w), __uint_as_float(v[2].x), __uint_as_float(v[2].y));
     L.o = mk3(__uint_as_float(v[2].z), __uint_as_float(v[2].w), __uint_as_float(v[3].x));
     L.d = mk3(__uint_as_float(v[3].y), __uint_as_float(v[3].z), __uint_as_float(v[3].w));
     L.inv = mk3(__uint_as_float(v[4].x), __uint_as_float(v[4].y), __uint_as_float(v[4].z));
     L.dist_march = __uint_as_float(v[4].w);
-    L.cand_data = (int)v[5].w;
-    L.h.distance = __uint_as_float(v[6].x);
-    L.h.normal = mk3(__uint_as_float(v[6].y), __uint_as_float(v[6].z), __uint_as_float(v[6].w));
-    L.h.color = f4{__uint_as_float(v[7].x), __uint_as_float(v[7].y), __uint_as_float(v[7].z), 0.0f};
-    L.h.emittance = __uint_as_float(v[7].w);
+    L.h.distance = __uint_as_float(v[H].x);
+    L.h.normal = mk3(__uint_as_float(v[H].y), __uint_as_float(v[H].z), __uint_as_float(v[H].w));
+    L.h.color = f4{__uint_as_float(v[H + 1].x), __uint_as_float(v[H + 1].y), __uint_as_float(v[H + 1].z), 0.0f};
+    L.h.emittance = __uint_as_float(v[H + 1].w);
 }
 
 // LDS traffic between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order; the fence keeps
@@ -1391,6 +1402,9 @@ DEV void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef CHUNKY_SWAP_XCHG
+#define CHUNKY_SWAP_XCHG 1  // a swap trades registers and parked record with LDS exchanges, in place (measured: +2 %)
+#endif
 // Lanes whose path does not wait for phase X trade it for a parked path that does (as many as both sides have).
 // Lanes that hold nothing any more (ST_DONE) give their place up first.  Returns the number of swaps.
 //
@@ -1420,10 +1434,21 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
         const int s = e & 0xFF;
         uint4 mine[WORDS], theirs[WORDS];
         pool_pack<WORDS>(L, mine);
+#if CHUNKY_SWAP_XCHG
+        // one LDS exchange per 8 bytes: the parked record and the lane's registers trade places in place
+#pragma unroll
+        for (int g = 0; g < WORDS; g++) {
+            unsigned long long* q = (unsigned long long*)&P.park[g * K + s];
+            const unsigned long long lo = __hip_atomic_exchange(q, (unsigned long long)mine[g].x | ((unsigned long long)mine[g].y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const unsigned long long hi = __hip_atomic_exchange(q + 1, (unsigned long long)mine[g].z | ((unsigned long long)mine[g].w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            theirs[g] = make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+        }
+#else
 #pragma unroll
         for (int g = 0; g < WORDS; g++) theirs[g] = P.park[g * K + s];
 #pragma unroll
         for (int g = 0; g < WORDS; g++) P.park[g * K + s] = mine[g];
+#endif
         st = e >> 8;
         pool_unpack<WORDS>(L, theirs);
         L.top_idx = -1;  // the cached top-level entry belonged to the path that left
@@ -1544,7 +1569,7 @@ DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) {
 #define CHUNKY_POOL_WAVES 6  // waves per SIMD: the march is bound by the latency of its two dependent tree reads, every wave counts
 #endif
 #ifndef CHUNKY_POOL_PARK
-#define CHUNKY_POOL_PARK 48  // paths parked per wave (LDS: 136 bytes each)
+#define CHUNKY_POOL_PARK 56  // paths parked per wave (LDS: 7 x 16 + 8 bytes each; 6 x 4 waves x 56 fill 158 of 160 KB)
 #endif
 constexpr int kPoolPark = CHUNKY_POOL_PARK;
 #ifndef CHUNKY_POOL_REFILL
@@ -1588,7 +1613,7 @@ constexpr int kWWalk = CHUNKY_W_WALK, kWBvh = CHUNKY_W_BVH, kWLeaf = CHUNKY_W_LE
 #endif
 template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false>
 __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
-    constexpr int WORDS = EXT ? 9 : 8;  // 16-byte words of a parked path
+    constexpr int WORDS = EXT ? 9 : (BVH ? 8 : 7);  // 16-byte words of a parked path (pool_pack)
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -2168,7 +2193,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     typedef void (*Kernel)(WaveArgs);
     Kernel k;
     const bool ext = opts_extended(O);  // EXPERIMENTAL light-transport options: their own instantiations
-    int words = 8;
+    int words = bvh ? 8 : 7;
     if (ext) {
         if (tree != 17 && tree != 18) tree = -1;
         words = 9;
@@ -2241,7 +2266,9 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
                          float* staging) {
     const bool any_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
     // render_pool: always without entity BVHs; with them when they could be re-laid out (rt_device.hpp bvh_rec / tri_rec)
-    if (!(variant & 2) && !(variant & 8) && work_counter && staging && (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1))))
+    // (its 7-word parked record counts march steps in 16 bits: a larger draw depth runs render_waves)
+    const bool steps_fit = any_bvh || opts_extended(O) || O.draw_depth <= 65535;
+    if (!(variant & 2) && !(variant & 8) && work_counter && staging && steps_fit && (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1))))
         return launch_pool(variant, S, C, O, T, P, res, work_counter, stream, chosen, staging);
     if (!(variant & 2) && work_counter) {
         const bool stats = (variant & 4) != 0;  // work_counter[2..] = 9 x u64 phase profile

@@ -540,29 +540,42 @@ DEV bool bvh_hit(const SceneView& S, const int* __restrict__ bvh, f3 o, f3 d, Hi
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sky_intersect — K/sky.h:95-106 with the linear / mirrored-repeat sampler contract of rt_math.h
-DEV f4 sky_color(const SceneView& S, f3 d) {
+// Sky_intersect — K/sky.h:95-106 with the linear / mirrored-repeat sampler contract of rt_math.h, in two halves: the
+// four texel reads are issued by sky_fetch, their weighted sum is taken by sky_blend — intersectSky puts the sun-disc
+// test (two acos and a dependent texel read of its own) between them, so the two round trips to memory overlap.
+struct SkyTexels {
+    float4 t00, t10, t01, t11;
+    float a, b;
+};
+DEV SkyTexels sky_fetch(const SceneView& S, f3 d) {
     float theta = rt_atan2(d.z, d.x);
     theta = theta / (RT_PI_F * 2);
     theta = rt_fmod1(rt_fmod1(theta) + 1);
     float phi = (rt_asin(rt_clamp(d.y, -1.0f, 1.0f)) + RT_PI_2_F) * RT_1_PI_F;
     int i0, i1, j0, j1;
-    float a, b;
-    rt_mirror_linear(theta, S.sky_w, &i0, &i1, &a);
-    rt_mirror_linear(phi, S.sky_h, &j0, &j1, &b);
-    const float4 t00 = S.sky[j0 * S.sky_w + i0], t10 = S.sky[j0 * S.sky_w + i1];
-    const float4 t01 = S.sky[j1 * S.sky_w + i0], t11 = S.sky[j1 * S.sky_w + i1];
+    SkyTexels k;
+    rt_mirror_linear(theta, S.sky_w, &i0, &i1, &k.a);
+    rt_mirror_linear(phi, S.sky_h, &j0, &j1, &k.b);
+    k.t00 = S.sky[j0 * S.sky_w + i0];
+    k.t10 = S.sky[j0 * S.sky_w + i1];
+    k.t01 = S.sky[j1 * S.sky_w + i0];
+    k.t11 = S.sky[j1 * S.sky_w + i1];
+    return k;
+}
+DEV f4 sky_blend(const SceneView& S, const SkyTexels& q) {
+    const float a = q.a, b = q.b;
     float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     float k = S.sky_intensity;
     // the alpha channel is sampled by the reference too but never read again (K/kernel.h:30)
-    return f4{(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x) * k,
-              (w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y) * k,
-              (w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z) * k, 0.0f};
+    return f4{(w00 * q.t00.x + w10 * q.t10.x + w01 * q.t01.x + w11 * q.t11.x) * k,
+              (w00 * q.t00.y + w10 * q.t10.y + w01 * q.t01.y + w11 * q.t11.y) * k,
+              (w00 * q.t00.z + w10 * q.t10.z + w01 * q.t01.z + w11 * q.t11.z) * k, 0.0f};
 }
+DEV f4 sky_color(const SceneView& S, f3 d) { return sky_blend(S, sky_fetch(S, d)); }
 
 // Sun_intersect — K/sky.h:42-66: adds the sun-disc texel (x intensity) to c
 DEV void sun_disc(const SceneView& S, f3 d, f4& c) {
-    if (!(S.sun_flags & 1) || dot(d, S.sw) < 0.5f) return;
+    if (!(S.sun_flags & 1) || dot(d, S.sw) < 0.5f) return;  // (c + 0 would turn a -0 channel into +0)
     const float radius = 0.03f;
     const float width = radius * 4;
     const float width2 = width * 2;
@@ -580,8 +593,30 @@ DEV void sun_disc(const SceneView& S, f3 d, f4& c) {
 
 // intersectSky — K/kernel.h:26-31: returns color.xyz * throughput * emittance
 DEV f3 sky_radiance(const SceneView& S, f3 d, f3 throughput, float emittance) {
-    f4 c = sky_color(S, d);
-    sun_disc(S, d, c);
+    const SkyTexels q = sky_fetch(S, d);
+    // the disc's texel, fetched while the sky's four are on their way; `in_disc` keeps "+= texel" apart from "no add"
+    bool in_disc = false;
+    f3 add = mk3(0, 0, 0);
+    if ((S.sun_flags & 1) && !(dot(d, S.sw) < 0.5f)) {
+        const float radius = 0.03f;
+        const float width = radius * 4;
+        const float width2 = width * 2;
+        float a = RT_PI_2_F - rt_acos(dot(d, S.su)) + width;
+        if (a >= 0 && a < width2) {
+            float b = RT_PI_2_F - rt_acos(dot(d, S.sv)) + width;
+            if (b >= 0 && b < width2) {
+                f4 t = unpack_unorm8(atlas_texel(S, a / width2, b / width2, S.sun_tex, S.sun_tex_size));
+                add = mk3(t.x * S.sun_intensity, t.y * S.sun_intensity, t.z * S.sun_intensity);
+                in_disc = true;
+            }
+        }
+    }
+    f4 c = sky_blend(S, q);
+    if (in_disc) {
+        c.x += add.x;
+        c.y += add.y;
+        c.z += add.z;
+    }
     return (mk3(c.x, c.y, c.z) * throughput) * emittance;
 }
 

@@ -34,7 +34,7 @@ def assert_radiance(got, want, what):
     pytest.fail(f"{what}: within {REL_TOL} but not bit-exact ({bad} values differ) — the arithmetic contract is broken")
 
 
-# CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (render_pool, 48 parked paths per wave, wide-tree
+# CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (render_pool, 56 parked paths per wave, wide-tree
 # lookup), bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes),
 # bit 3 = the grouped kernel render_waves (always used for scenes with entity BVHs) with bits 4-5 = its lanes per pixel
 # forced to 1 / 8 / 16, bits 6-7 = render_pool with no / 32 / 64 parked paths
@@ -222,6 +222,24 @@ def test_render_loop_options_match_oracle(gpu_instance, port, name, draw, depth,
         want = port.render_passes(sc, seeds)
     assert_radiance(got, want, f"{name} draw {draw} depth {depth} scale {scale}")
     assert not np.array_equal(bits(want), bits(port.render_passes(sc, seeds))), "the options changed nothing"
+    r.close()
+    loader.close()
+
+
+def test_draw_depth_above_16_bits(gpu_instance, port):
+    """render_pool's parked record counts march steps in 16 bits: a draw depth above 65535 must run another kernel
+    (render_waves) and still give the reference's image (the depth never binds in a world this small)."""
+    sc = gs.make("outdoor").with_view(64, 40)
+    seeds = scenes.java_random_ints(2)
+    loader, r = make_renderer(gpu_instance, sc)
+    r.set_option(native.OPT_DRAW_DEPTH, 65535)
+    r.render_passes(seeds)
+    assert r.kernel_info()["pool"] >= 0
+    r.reset()
+    r.set_option(native.OPT_DRAW_DEPTH, 1 << 20)
+    r.render_passes(seeds)
+    assert r.kernel_info()["pool"] < 0, r.kernel_info()
+    assert_radiance(r.read(), port.render_passes(sc, seeds), "draw depth 2^20")
     r.close()
     loader.close()
 

@@ -53,13 +53,13 @@ def outdoor():
 
 
 def test_headline_kernel_128_passes(gpu_instance, port, outdoor):
-    """bench.py's step: one 128-pass launch of render_pool<17, 48> (+ fold_kernel) over the whole 1080p image."""
+    """bench.py's step: one 128-pass launch of render_pool<17, 56> (+ fold_kernel) over the whole 1080p image."""
     sc = outdoor
     seeds = native.java_random_ints(128)
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"], info["bvh"]) == (17, 48, False), info
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
     assert info["blocks"] >= 256 * 4
     compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[::2]), "outdoor 128 passes")
     # the second step of the bench continues the running mean at bufferSpp = 128 (K/rayTracer.cl:109-112)
@@ -89,7 +89,7 @@ def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group,
     r.render_passes(seeds)
     info = r.kernel_info()
     if variant == 0:
-        assert (info["tree"], info["pool"], info["bvh"]) == (17, 48, False), info
+        assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
     else:
         assert (info["tree"], info["group"], info["bvh"], info["pool"]) == (17, group, False, -1), info
     own = parallel.owned_gids(sc.width * sc.height, rank, world, 256)
@@ -104,20 +104,20 @@ def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group,
 
 
 def test_city_kernel(gpu_instance, port):
-    """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_pool<18, 48>."""
+    """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_pool<18, 56>."""
     from chunkyclplugin_amd import octree2
     sc = octree2.cached_benchmark_scene(1920, 1080)   # raises when the fixture is missing: never skipped silently
     seeds = native.java_random_ints(64)
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"], info["bvh"]) == (18, 48, False), info
+    assert (info["tree"], info["pool"], info["bvh"]) == (18, 56, False), info
     compare_rows(r, port, sc, seeds, row_gids(sc), "city 64 passes")
     r.set_shard(3, 8, 256)
     r.reset()
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"]) == (18, 48), info
+    assert (info["tree"], info["pool"]) == (18, 56), info
     own = parallel.owned_gids(sc.width * sc.height, 3, 8, 256)
     compare_rows(r, port, sc, seeds, np.intersect1d(row_gids(sc), own), "city share 1/8")
     r.close()
@@ -173,7 +173,7 @@ def test_indoor_kernel(gpu_instance, port):
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"], info["bvh"]) == (17, 48, False), info
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
     compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[1::2]), "indoor 32 passes")
     r.close()
     loader.close()
