@@ -1311,3 +1311,22 @@ extern "C" int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const flo
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return CHUNKY_OK;
 }
+
+extern "C" int chunky_selftest_gamma_scan(chunky_ctx* ctx, int curve, uint32_t first_bits, uint64_t count, uint64_t* mismatches, float* worst_estimate) {
+    if (!ctx || !mismatches) return fail(CHUNKY_E_INVALID, "selftest_gamma_scan: NULL argument");
+    if (count > (1ull << 32) || (curve != 0 && curve != 2)) return fail(CHUNKY_E_INVALID, "selftest_gamma_scan: curve=%d count=%llu", curve, (unsigned long long)count);
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const float* table = nullptr;
+    if (int rc = device_gamma_table(ctx, &table)) return rc;
+    DevBuf out;
+    HIP_TRY(hipMalloc(&out.p, 16));
+    HIP_TRY(hipMemsetAsync(out.p, 0, 16, ctx->stream));
+    HIP_TRY(launch_gamma_scan(first_bits, count, curve, table, (unsigned long long*)out.p, (float*)((char*)out.p + 8), ctx->stream));
+    unsigned char host[16];
+    HIP_TRY(hipMemcpyAsync(host, out.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(mismatches, host, 8);
+    if (worst_estimate) memcpy(worst_estimate, host + 8, 4);
+    return CHUNKY_OK;
+}

@@ -66,6 +66,10 @@ hipError_t launch_preview(int variant, const SceneView& S, const CameraView& C, 
 // thresholds: 256 floats on the device (capi.hip gamma_thresholds) or null = evaluate pow per channel
 hipError_t launch_filter(long long n_pixels, float exposure, const double* in, unsigned* out, int type, hipStream_t stream,
                          const float* thresholds = nullptr);
+// tone map self test: gamma_bytes3 (curve 0) / aces_bytes3 (curve 2) against the reference's arithmetic and a search of the
+// threshold table, for `count` consecutive float bit patterns
+hipError_t launch_gamma_scan(unsigned first, unsigned long long count, int curve, const float* thresholds, unsigned long long* mismatches,
+                             float* worst, hipStream_t stream);
 hipError_t launch_math_selftest(int which, int n, const float* a, const float* b, float* out, hipStream_t stream);
 
 }  // namespace chunky

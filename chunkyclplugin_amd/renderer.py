@@ -60,6 +60,12 @@ class RendererInstance:
         check(native.lib().chunky_selftest_math(self._h, which, a.size, ptr(a), ptr(b), ptr(out)))
         return out
 
+    def selftest_gamma_scan(self, curve: int, first_bits: int, count: int):
+        """(values whose tone-map byte differs from the threshold table's, worst stray of the estimate) over `count` float bit patterns."""
+        bad, worst = C.c_uint64(0), C.c_float(0)
+        check(native.lib().chunky_selftest_gamma_scan(self._h, curve, first_bits, count, C.byref(bad), C.byref(worst)))
+        return int(bad.value), float(worst.value)
+
     def close(self) -> None:
         if self._h:
             check(native.lib().chunky_shutdown(self._h))

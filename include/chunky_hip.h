@@ -250,6 +250,14 @@ int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int depth, const
 /* ---- self test: evaluate the rt_math.h contract on the device (bit-compared with the host by tests) */
 int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const float* a, const float* b, float* out);
 
+/* ---- self test of the tone map's byte estimate (no reference counterpart): `count` consecutive float bit patterns from
+ * first_bits through the fast path of the GAMMA (curve 0) or ACES (curve 2) filter (hardware log2 / exp2 / reciprocal
+ * estimate, settled against the threshold table — ACES: after the correctly rounded division — only near a step) and
+ * through the reference's arithmetic (post_processing_filter.cl:33-38 for ACES) followed by a plain search of
+ * chunky_filter_gamma_thresholds' table; *mismatches = values whose bytes differ (must be 0), *worst_estimate = the
+ * furthest an estimate strayed beyond its byte's interval (may be NULL). */
+int chunky_selftest_gamma_scan(chunky_ctx* ctx, int curve, uint32_t first_bits, uint64_t count, uint64_t* mismatches, float* worst_estimate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,6 +142,23 @@ def test_gpu_gamma_thresholds_edge_values(gpu_instance, port):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("curve", [0, 2])
+def test_gpu_gamma_fast_path_every_float(gpu_instance, curve):
+    """The device evaluates the GAMMA / ACES byte from a hardware log2 / exp2 (ACES: and reciprocal) estimate and consults the
+    threshold table (ACES: after the correctly rounded division) only when the estimate lies within 1/8192 of a step.  That
+    is the byte of the reference's arithmetic for EVERY float: all 2^32 bit patterns (NaNs, negative values, denormals,
+    infinities included) through both, and the estimate never strays further beyond its byte's interval than a quarter of
+    the guard band."""
+    bad, worst = 0, 0.0
+    for part in range(4):
+        b, w = gpu_instance.selftest_gamma_scan(curve, part << 30, 1 << 30)
+        bad += b
+        worst = max(worst, w)
+    assert bad == 0
+    assert worst < 0.25 / 8192, worst
+
+
+@pytest.mark.gpu
 def test_gpu_filter_matches_reference_goldens(gpu_instance):
     from chunkyclplugin_amd.renderer import HipPostProcessingFilter
     g = np.load(GOLD)
