@@ -811,9 +811,10 @@ extern "C" int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int wi
     r->own_fb.bytes = bytes;
     r->fb = (float*)r->own_fb.p;
     HIP_TRY(hipMemsetAsync(r->fb, 0, bytes, ctx->stream));
-    HIP_TRY(hipMalloc(&r->work_counter.p, 256));
-    r->work_counter.bytes = 256;
-    HIP_TRY(hipMemsetAsync(r->work_counter.p, 0, 256, ctx->stream));
+    // [0] the sample / pixel queue, [2..49] the phase profile, [64..127] render_pool's range counters (kernels.hip xcd_claim)
+    HIP_TRY(hipMalloc(&r->work_counter.p, 512));
+    r->work_counter.bytes = 512;
+    HIP_TRY(hipMemsetAsync(r->work_counter.p, 0, 512, ctx->stream));
     r->shard = ShardView{0, 1, 256, width * height};
     scene->refs++;
     *out = r.release();

@@ -636,6 +636,7 @@ struct WaveArgs {
     unsigned stack_bytes;  // size of the BVH-stack area at the start of dynamic LDS
     float* staging;        // render_pool: radiance of every sample of the launch, [tile][pass][slot in tile][3]
     unsigned n_samples;    // render_pool: tiles of kSampleTile pixel slots (the last one padded) x P.n
+    unsigned xcd_stripe;   // render_pool: samples per range (xcd_claim): the tiles over kXcdRanges, rounded up, x P.n x kSampleTile
 };
 static_assert(sizeof(WaveArgs) <= 4096, "launch arguments must fit the 4 KB kernel-argument segment");
 typedef const WaveArgs __attribute__((address_space(4))) * WaveArgPtr;
@@ -1592,6 +1593,79 @@ constexpr int kModelBatch = CHUNKY_MODEL_BATCH;  // model-block candidates that 
 constexpr int kPoolRefill = CHUNKY_POOL_REFILL;  // leave the march loop to refill once this many lanes are free and parked marchers exist
 constexpr int kSampleBatch = 256;                // sample indices a wave claims per atomic
 
+// Samples are handed out per XCD.  Each of the eight XCDs has its own L2, and workgroup b of a launch runs on XCD b % 8 (read
+// from the hardware: HW_REG_XCC_ID).  The launch's samples — tile-major, so a contiguous range is a stripe of the image with
+// all its passes — are cut into kXcdRanges equal ranges with a counter each; a wave starts in a range of the XCD it runs on
+// and, when that has run dry (sky stripes finish long before terrain stripes), goes on with the range that follows, where its
+// neighbours already are.  The waves that share an L2 — and the paths that share a wave's pool — thus work on neighbouring
+// tiles of one stripe, rays of one kind, while the chip as a whole is spread over the image.  Which wave renders a sample
+// has no influence on its value.  Measured on the bench (one counter: 5.55 Gsamples/s): eight stripes 5.92; going on with
+// the fullest range instead of the next 5.77; tile groups dealt round-robin to the XCDs instead of stripes: groups of 1-8
+// tiles -0.6 ... +0.9 %, 16-240 tiles +3 %.
+#ifndef CHUNKY_XCD_QUEUES
+#define CHUNKY_XCD_QUEUES 1
+#endif
+#ifndef CHUNKY_XCD_RANGES_PER_XCD
+#define CHUNKY_XCD_RANGES_PER_XCD 1
+#endif
+constexpr int kXcdRanges = 8 * CHUNKY_XCD_RANGES_PER_XCD;  // at most 64
+constexpr int kXcdCounters = 64;  // the range counters sit at work_counter[64 ...] (behind the claim counter and the 24 profile words)
+DEV int xcd_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return (int)(x & 7u);
+}
+// the range a wave starts in: the XCD's ranges are consecutive, its workgroups take them in turn
+DEV int xcd_first_range() { return xcd_id() * CHUNKY_XCD_RANGES_PER_XCD + (int)((blockIdx.x >> 3) % CHUNKY_XCD_RANGES_PER_XCD); }
+struct XcdClaim {
+    int q;               // the range this wave draws from; kXcdRanges + the ranges found empty so far, once its first one is
+    unsigned next, end;  // claimed and not yet handed out: samples [next, end) of the launch
+};
+// samples of range x: [x * stripe, min((x + 1) * stripe, n_samples)); stripe is a multiple of kSampleBatch
+DEV unsigned xcd_range_size(unsigned x, unsigned stripe, unsigned n_samples) {
+    const unsigned lo = x * stripe;
+    return lo >= n_samples ? 0u : (n_samples - lo < stripe ? n_samples - lo : stripe);
+}
+// Every lane with `need` gets a sample index: < n_samples a sample, kClaimNone nothing this time (the tail of a batch: the
+// lane asks again), kClaimDone no samples left anywhere.  Convergent.
+constexpr unsigned kClaimNone = 0xFFFFFFFEu, kClaimDone = 0xFFFFFFFFu;
+DEV unsigned xcd_claim(int* counters, XcdClaim& c, int& tried, bool need, unsigned stripe, unsigned n_samples) {
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0) return kClaimNone;
+    const unsigned n_need = (unsigned)__popcll(mask);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    const unsigned rem = c.end - c.next;
+    unsigned sidx = kClaimNone;
+    if (need && rank < rem) sidx = c.next + rank;
+    c.next += n_need < rem ? n_need : rem;
+    if (n_need > rem) {
+        bool got = false;
+        while (tried < kXcdRanges) {
+            int b = 0;
+            if (need && rank == 0) b = atomicAdd(counters + c.q, kSampleBatch);
+            const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(__shfl(b, __ffsll((long long)mask) - 1));
+            const unsigned n_q = xcd_range_size((unsigned)c.q, stripe, n_samples);
+            if (base < n_q) {
+                c.next = (unsigned)c.q * stripe + base;
+                c.end = c.next + (n_q - base < (unsigned)kSampleBatch ? n_q - base : (unsigned)kSampleBatch);
+                got = true;
+                break;
+            }
+            c.q = c.q + 1 == kXcdRanges ? 0 : c.q + 1;  // this range is empty for good: on to the next
+            tried += 1;
+        }
+        if (!got) {
+            if (need && rank >= rem) sidx = kClaimDone;
+            c.next = c.end = 0u;
+        } else {
+            const unsigned mine = c.next + (rank - rem);
+            if (need && rank >= rem && mine < c.end) sidx = mine;
+            c.next = c.next + (n_need - rem) < c.end ? c.next + (n_need - rem) : c.end;
+        }
+    }
+    return sidx;
+}
+
 // stats (STATS = true), same layout as render_waves: [0..8] executions / lanes / cycles of MARCH, BLOCK (and the entity-BVH
 // walk), SHADE; [9..11] wave lifetimes; [12] swap rounds, [13] paths swapped; [14..] parts of SHADE.
 #ifndef CHUNKY_W_WALK
@@ -1678,6 +1752,8 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
     unsigned long long t_begin = 0;
     if (STATS) t_begin = __builtin_amdgcn_s_memtime();
     PixelPool pool{0, 0};
+    XcdClaim claim{xcd_first_range(), 0u, 0u};
+    int ranges_tried = 0;  // ranges this wave has found empty
     int st = ST_FRESH;
     int ptag = lane < K ? ST_FRESH : ST_DONE;
     wave_lds_fence();
@@ -1827,8 +1903,12 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             //      thousand neighbouring pixels — a part of the scene that stays in the 4 MB L2s (pass-major order spread
             //      them over a third of the image: L2 hit rate 91 %, 66 GB of fabric reads per launch instead of 4) ----
             const bool need = st == ST_FRESH;
+#if CHUNKY_XCD_QUEUES
+            const unsigned sidx = xcd_claim(A->Q.next + kXcdCounters, claim, ranges_tried, need, A->xcd_stripe, A->n_samples);  // convergent
+#else
             const unsigned sidx = (unsigned)claim_slot<kSampleBatch>(arg_copy(&A->Q), pool, need);  // convergent
-            if (need) {
+#endif
+            if (need && sidx != kClaimNone) {
                 const unsigned n_samples = A->n_samples;
                 if (sidx >= n_samples) {
                     st = ST_DONE;
@@ -2319,7 +2399,10 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     if (chosen) *chosen = KernelChoice{tree, 1, bvh ? 1 : 0, grid, park, ext ? 1 : 0};
     e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
-    WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)depth, staging, (unsigned)n_samples};
+    e = hipMemsetAsync(work_counter + kXcdCounters, 0, kXcdRanges * sizeof(int), stream);  // the per-XCD sample ranges (xcd_claim)
+    if (e != hipSuccess) return e;
+    WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)depth, staging, (unsigned)n_samples,
+               (unsigned)((n_tiles + kXcdRanges - 1) / kXcdRanges * kSampleTile * P.n)};
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
