@@ -10,7 +10,7 @@ the metric is quoted on and it fits one GPU.  A "step" is `--passes` passes (sam
 over the whole image (default 128, so the default 8 steps are the 1024 spp BASELINE.json quotes the
 configuration at); scene upload is outside the timed region, the framebuffer lives in HBM.
 
-N > 1: one process per GPU, the scene replicated, the image cut into 256-pixel tiles dealt
+N > 1: one process per GPU, the scene replicated, the image cut into 16x16-pixel blocks dealt
 round-robin (chunky_render_set_shard), no collective on the data path, ONE RCCL reduce of the
 per-rank framebuffers to rank 0 inside the timed region (the read-back).  Total work is fixed as
 N grows => "scaling": "strong".
@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--chunks", type=int, default=32)
     ap.add_argument("--kernel", type=int, default=0, help="kernel variant (CHUNKY_OPT_KERNEL)")
-    ap.add_argument("--tile", type=int, default=256)
+    ap.add_argument("--tile", type=int, default=0, help="shard tiles: 0 = 16x16-pixel blocks (default), n > 0 = runs of n pixel indices")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
@@ -129,6 +129,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1:  # the read-back collective once, untimed, on a scratch buffer: communicator and channel set-up are not the path
+        parallel.reduce_framebuffer(torch.zeros_like(fb) if args.backend == "nccl" else torch.zeros(16), dst=0)
     spp = 0
     for _ in range(args.warmup):
         r.render_passes(seeds[spp:spp + args.passes], first_buffer_spp=spp, sync=False)
@@ -164,7 +166,7 @@ def main():
         np.save(args.dump, fb.cpu().numpy())
 
     if rank == 0:
-        local_slots = parallel.local_slots(n_pix, 0, args.emulate_world or world, args.tile)
+        local_slots = int(parallel.owned_gids(n_pix, 0, args.emulate_world or world, args.tile, sc.width).size)  # pixels rank 0 renders
         # an emulated share renders only rank 0's tiles: count what was rendered, and say so
         samples = (min(local_slots, n_pix) if args.emulate_world else n_pix) * args.steps * args.passes
         value = samples / dt / 1e6
@@ -205,7 +207,7 @@ def main():
                                    f"{sc.width}x{sc.height}, draw-depth 256, sun+sky, {args.passes} spp per step",
                        "passes_per_step": args.passes, "spp_timed": args.steps * args.passes,
                        "octree_ints": int(sc.octree.size), "octree_depth": int(sc.octree_depth),
-                       "parallelism": f"image tiles of {args.tile} px round-robin over {world} GPU(s), scene replicated, "
+                       "parallelism": f"image tiles ({'16x16-pixel blocks' if args.tile == 0 else f'runs of {args.tile} px'}) round-robin over {world} GPU(s), scene replicated, "
                                       f"one RCCL reduce per read-back", "kernel_variant": args.kernel},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

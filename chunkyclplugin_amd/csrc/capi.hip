@@ -129,8 +129,14 @@ struct chunky_render {
 
 constexpr size_t kStagingBytes = (size_t)8 << 30;  // 8 GiB: 1920x1080 x 256 passes is 6.4 GB (of 288)
 
-static int n_local_slots(int n_pixels, const ShardView& t) {
+static int n_local_slots(int width, int height, const ShardView& t) {
+    const int n_pixels = width * height;
     if (t.world == 1) return n_pixels;
+    if (t.tile == 0) {  // 16 x 16 blocks rank, rank + world, ... of the image, edge blocks padded
+        const int n_blocks = ((width + 15) / 16) * ((height + 15) / 16);
+        const int mine = (n_blocks - t.rank + t.world - 1) / t.world;
+        return mine > 0 ? mine * 256 : 0;
+    }
     int n_tiles = (n_pixels + t.tile - 1) / t.tile;
     int mine = (n_tiles - t.rank + t.world - 1) / t.world;  // tiles rank, rank+world, ...
     return mine > 0 ? mine * t.tile : 0;
@@ -895,9 +901,9 @@ extern "C" int chunky_render_set_option(chunky_render* r, int option, int32_t va
 
 extern "C" int chunky_render_set_shard(chunky_render* r, int rank, int world, int tile) {
     LOCK_RENDER(r);
-    if (world < 1 || rank < 0 || rank >= world || tile < 1) return fail(CHUNKY_E_INVALID, "set_shard: rank %d / world %d / tile %d", rank, world, tile);
+    if (world < 1 || rank < 0 || rank >= world || tile < 0) return fail(CHUNKY_E_INVALID, "set_shard: rank %d / world %d / tile %d", rank, world, tile);
     ShardView t{rank, world, tile, 0};
-    t.n_local = n_local_slots(r->width * r->height, t);
+    t.n_local = n_local_slots(r->width, r->height, t);
     r->shard = t;
     return CHUNKY_OK;
 }

@@ -3,9 +3,10 @@
 The reference is single-device; this is new.  One process per GPU (torch.distributed, backend
 "nccl" = RCCL over xGMI), the scene replicated, pixels sharded:
 
-* the pixel index range [0, W*H) is cut into tiles of `tile` consecutive gids; tile t belongs to
-  rank t % world (`chunky_render_set_shard` applies the same rule on the device: `shard_gid` in
-  csrc/kernels.hip);
+* the image is cut into tiles — blocks of 16 x 16 pixels (`tile` 0, the default of bench.py: the shape
+  the pool kernel renders in) or runs of `tile` consecutive pixel indices; tile t belongs to rank
+  t % world (`chunky_render_set_shard` applies the same rule on the device: `pool_slot_gid` /
+  `shard_gid` in csrc/kernels.hip);
 * every rank renders into a full-size framebuffer that stays zero outside its own tiles;
 * ONE collective per read-back: `reduce(SUM)` to rank 0.  Tiles are disjoint and x + 0 = x exactly,
   so the result is bit-identical to the 1-GPU image.  Nothing is exchanged per pass.
@@ -15,20 +16,31 @@ from __future__ import annotations
 import numpy as np
 
 
-def local_slots(n_pixels: int, rank: int, world: int, tile: int) -> int:
-    """Pixel slots (whole tiles) owned by `rank` — ShardView.n_local on the device."""
+def local_slots(n_pixels: int, rank: int, world: int, tile: int, width: int = 0) -> int:
+    """Pixel slots (whole tiles, padding included) owned by `rank` — ShardView.n_local on the device.
+    tile = 0: 16 x 16 blocks of an image `width` pixels wide; tile > 0: runs of `tile` pixel indices."""
     if world == 1:
         return n_pixels
+    if tile == 0:
+        assert width > 0 and n_pixels % width == 0, "block shards need the image width"
+        n_blocks = ((width + 15) // 16) * ((n_pixels // width + 15) // 16)
+        return max((n_blocks - rank + world - 1) // world, 0) * 256
     n_tiles = (n_pixels + tile - 1) // tile
     mine = (n_tiles - rank + world - 1) // world
     return max(mine, 0) * tile
 
 
-def owned_gids(n_pixels: int, rank: int, world: int, tile: int = 256) -> np.ndarray:
+def owned_gids(n_pixels: int, rank: int, world: int, tile: int = 256, width: int = 0) -> np.ndarray:
     """Global pixel indices rendered by `rank`, in the order the device queue hands them out."""
-    slots = np.arange(local_slots(n_pixels, rank, world, tile), dtype=np.int64)
+    slots = np.arange(local_slots(n_pixels, rank, world, tile, width), dtype=np.int64)
     if world == 1:
         return slots.astype(np.int32)
+    if tile == 0:
+        height, bw = n_pixels // width, (width + 15) // 16
+        b = (slots // 256) * world + rank
+        x, y = (b % bw) * 16 + (slots % 16), (b // bw) * 16 + (slots % 256) // 16
+        ok = (x < width) & (y < height)
+        return (y * width + x)[ok].astype(np.int32)
     t, w = slots // tile, slots % tile
     gid = (t * world + rank) * tile + w
     return gid[gid < n_pixels].astype(np.int32)

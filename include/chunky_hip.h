@@ -116,7 +116,10 @@ typedef enum chunky_option {
 int chunky_render_set_option(chunky_render* r, int option, int32_t value);
 
 /* Multi-GPU image-tile ownership (no reference counterpart — the reference is single-device):
- * pixel indices are cut into tiles of `tile` consecutive gids, tile t belongs to rank t % world.
+ * tile = 0: the image is cut into blocks of 16 x 16 pixels (row-major over blocks, edge blocks
+ * partial), block b belongs to rank b % world — the shape the pool kernel renders in, so a share
+ * runs as fast per pixel as the whole image (other kernels refuse it); tile > 0: pixel indices are
+ * cut into runs of `tile` consecutive gids, run t belongs to rank t % world (every kernel).
  * A rank renders only its tiles; every other pixel of its buffer stays 0, so a SUM reduce over
  * ranks (one RCCL collective per read-back) reproduces the 1-GPU image bit for bit. */
 int chunky_render_set_shard(chunky_render* r, int rank, int world, int tile);

@@ -30,7 +30,7 @@ def _worker(rank, world, port, tile, out_path):
         n = sc.width * sc.height
         seeds = scenes.java_random_ints(3)
         fb = np.zeros(3 * n, np.float32)
-        gids = parallel.owned_gids(n, rank, world, tile)
+        gids = parallel.owned_gids(n, rank, world, tile, sc.width)
         binding.port().render_gids(sc, seeds, gids, res=fb, threads=2)
         t = torch.from_numpy(fb)
         parallel.reduce_framebuffer(t, dst=0)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, tile, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tile", [256, 100])
+@pytest.mark.parametrize("tile", [0, 256, 100])
 def test_two_ranks_reduce_to_the_single_rank_image(tmp_path, port, tile):
     out = str(tmp_path / "fb.npy")
     mp.spawn(_worker, args=(2, _free_port(), tile, out), nprocs=2, join=True)
@@ -59,4 +59,19 @@ def test_tiles_partition_the_image(world, tile, n):
         seen[g] += 1
         if world > 1 and g.size:
             assert ((g // tile) % world == r).all()
+    assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("world,width,height", [(2, 64, 40), (3, 100, 37), (8, 1920, 1080), (5, 16, 16), (4, 15, 3)])
+def test_blocks_partition_the_image(world, width, height):
+    """tile = 0: the 16 x 16 blocks of the image (edge blocks partial), block b to rank b % world."""
+    n = width * height
+    seen = np.zeros(n, np.int32)
+    for r in range(world):
+        g = parallel.owned_gids(n, r, world, 0, width)
+        assert parallel.local_slots(n, r, world, 0, width) >= g.size
+        seen[g] += 1
+        if g.size:
+            b = (g // width // 16) * ((width + 15) // 16) + (g % width) // 16
+            assert (b % world == r).all()
     assert (seen == 1).all()

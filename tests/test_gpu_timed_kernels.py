@@ -103,6 +103,37 @@ def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group,
     loader.close()
 
 
+@pytest.mark.parametrize("world,rank,passes", [(2, 1, 32), (8, 5, 64), (3, 0, 32)])
+def test_outdoor_block_shards(gpu_instance, port, outdoor, world, rank, passes):
+    """The split bench.py --gpus N uses (chunky_render_set_shard with tile 0): the image's 16 x 16 blocks dealt round-robin,
+    rendered by the pool kernel in the same tile shape as the whole image.  The rank's pixels of whole image rows (the half-
+    padded bottom block row of 1080 lines included) against the oracle, everybody else's stay zero, and the ranks' pixel
+    sets partition the image; the grouped kernel refuses the mode."""
+    sc = outdoor
+    n = sc.width * sc.height
+    seeds = native.java_random_ints(passes)
+    loader, r = make(gpu_instance, sc)
+    r.set_shard(rank, world, 0)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
+    own = parallel.owned_gids(n, rank, world, 0, sc.width)
+    rows = row_gids(sc, ROWS + (1072,))
+    mine = np.intersect1d(rows, own)
+    assert abs(mine.size - rows.size / world) < 0.02 * rows.size + 32
+    compare_rows(r, port, sc, seeds, mine, f"outdoor block share {rank}/{world}")
+    img = r.read().reshape(-1, 3)
+    mask = np.ones(n, bool)
+    mask[own] = False
+    assert not img[mask].any()                     # every pixel of the other ranks stays zero (the reduce adds them)
+    assert np.count_nonzero(img[own].any(axis=1)) > 0.9 * own.size
+    r.set_option(native.OPT_KERNEL, 8)
+    with pytest.raises(Exception):
+        r.render_passes(seeds[:2])
+    r.close()
+    loader.close()
+
+
 def test_city_kernel(gpu_instance, port):
     """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_pool<18, 56>."""
     from chunkyclplugin_amd import octree2
