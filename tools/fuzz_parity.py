@@ -29,6 +29,8 @@ def main():
         size = int(rng.choice([16, 32, 48]))
         ents = int(rng.choice([0, 0, 24, 120]))
         w, h = int(rng.integers(5, 90)), int(rng.integers(3, 60))
+        if rng.random() < 0.15:  # a few hundred tiles: every XCD range of render_pool's sample queue has work
+            w, h = int(rng.integers(150, 400)), int(rng.integers(100, 260))
         sc = scenes.tiny_scene(seed=int(rng.integers(1, 10 ** 6)), size=size, width=w, height=h, entities=ents, sun_flag=bool(rng.random() < 0.7))
         if rng.random() < 0.3:   # look from inside / from far outside the world
             S = float(1 << sc.octree_depth)
@@ -49,6 +51,8 @@ def main():
         draw, depth, scale = int(rng.choice([256, 256, 40, 3])), int(rng.choice([5, 5, 1, 2, 9])), float(rng.choice([13.0, 13.0, 0.0, 2.5]))
         world = int(rng.choice([1, 1, 2, 3, 8]))
         rank, tile = int(rng.integers(0, world)), int(rng.choice([256, 64, 100]))
+        if variant in (0, 64, 128, 192) and rng.random() < 0.5:
+            tile = 0  # 16 x 16 blocks (the pool kernel only)
         seeds = native.java_random_ints(passes, seed=int(rng.integers(0, 10 ** 6)))
         loader = HipSceneLoader(inst)
         loader.load_packed(sc)
@@ -63,7 +67,7 @@ def main():
         r.set_shard(rank, world, tile)
         r.render_passes(seeds, first_buffer_spp=first)
         got = r.read()
-        own = parallel.owned_gids(w * h, rank, world, tile)
+        own = parallel.owned_gids(w * h, rank, world, tile, w)
         want = np.zeros(3 * w * h, np.float32)
         with PortOptions(port, draw, depth, scale):
             if ext:
