@@ -7,8 +7,10 @@
 Workload (config.workload): BASELINE.json configs[2] — the synthetic 32x32-chunk outdoor world at
 1920x1080, draw-depth 256, sun + sky, seeds from java.util.Random(0) — because that is the scene
 the metric is quoted on and it fits one GPU.  A "step" is `--passes` passes (samples per pixel)
-over the whole image (default 128, so the default 8 steps are the 1024 spp BASELINE.json quotes the
-configuration at); scene upload is outside the timed region, the framebuffer lives in HBM.
+over the whole image, one launch (default 256, the most a launch carries, so the default 4 steps are
+the 1024 spp BASELINE.json quotes the configuration at; every launch ends with a ~0.75 ms tail in which
+the longest paths of its last samples finish, so fewer, longer launches waste less — 1 % at N = 1, 7 %
+of an eighth share); scene upload is outside the timed region, the framebuffer lives in HBM.
 
 N > 1: one process per GPU, the scene replicated, the image cut into 16x16-pixel blocks dealt
 round-robin (chunky_render_set_shard), no collective on the data path, ONE RCCL reduce of the
@@ -66,9 +68,9 @@ def oracle_row_sample(sc, seeds, rows, threads, count: bool):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--passes", type=int, default=128, help="passes (spp) per step; one launch carries up to 256")
+    ap.add_argument("--passes", type=int, default=256, help="passes (spp) per step; one launch carries up to 256")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--chunks", type=int, default=32)

@@ -52,23 +52,23 @@ def outdoor():
     return scenes.cached_outdoor_world(chunks=32, height=256)  # BASELINE configs[2], 1920x1080: what bench.py renders
 
 
-def test_headline_kernel_128_passes(gpu_instance, port, outdoor):
-    """bench.py's step: one 128-pass launch of render_pool<17, 56> (+ fold_kernel) over the whole 1080p image."""
+def test_headline_kernel_256_passes(gpu_instance, port, outdoor):
+    """bench.py's step: one 256-pass launch of render_pool<17, 56> (+ fold_kernel) over the whole 1080p image."""
     sc = outdoor
-    seeds = native.java_random_ints(128)
+    seeds = native.java_random_ints(256)
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
     assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
     assert info["blocks"] >= 256 * 4
-    compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[::2]), "outdoor 128 passes")
-    # the second step of the bench continues the running mean at bufferSpp = 128 (K/rayTracer.cl:109-112)
-    more = native.java_random_ints(160)[128:]
-    r.render_passes(more, first_buffer_spp=128)
+    compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[::3]), "outdoor 256 passes")
+    # the second step of the bench continues the running mean at bufferSpp = 256 (K/rayTracer.cl:109-112)
+    more = native.java_random_ints(288)[256:]
+    r.render_passes(more, first_buffer_spp=256)
     g = row_gids(sc, (263, 931))
     got = r.read().reshape(-1, 3)[g]
     want = port.render_gids(sc, seeds, g, threads=THREADS)
-    want = port.render_gids(sc, more, g, first_spp=128, res=want, threads=THREADS).reshape(-1, 3)[g]
+    want = port.render_gids(sc, more, g, first_spp=256, res=want, threads=THREADS).reshape(-1, 3)[g]
     np.testing.assert_array_equal(bits(got), bits(want))
     r.close()
     loader.close()

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r02s; mkdir -p $O; cd $R
 for n in 1 2 4 8; do
   if [ $n = 1 ]; then E=""; else E="--emulate-world $n"; fi
-  timeout 200 python3 bench.py --no-cpu --no-roofline --steps 8 $E 2>/dev/null | python3 -c "
+  timeout 200 python3 bench.py --no-cpu --no-roofline --steps 4 $E 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); print(json.dumps({'world': $n, 'Msamples/s_of_share': d['value'], 'ms_per_step': d['ms_per_step'], 'launch_ms': d['roofline']['launch_ms'], 'kernel': d['roofline']['kernel']}))" | tee -a $O/emulated_scaling.jsonl
 done
