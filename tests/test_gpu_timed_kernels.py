@@ -239,6 +239,28 @@ def test_entity_kernels(gpu_instance, port, entity_world, world, passes, group, 
     loader.close()
 
 
+def test_entity_config_at_its_stated_size(gpu_instance, port, entity_world):
+    """BASELINE configs[4] as stated — 3840 x 2160, tiles split over 8 GPUs: what one GPU of the eight renders (rank 5's
+    16 x 16 blocks), on this one GPU, against the oracle on that rank's pixels of five image rows; nobody else's pixels
+    are touched."""
+    sc = entity_world.with_view(3840, 2160)
+    seeds = native.java_random_ints(8)
+    loader, r = make(gpu_instance, sc)
+    r.set_shard(5, 8, 0)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["bvh"]) == (17, True) and info["pool"] in (16, 32), info
+    own = parallel.owned_gids(sc.width * sc.height, 5, 8, 0, sc.width)
+    assert abs(own.size - sc.width * sc.height / 8) < 4096
+    mine = np.intersect1d(row_gids(sc, (203, 822, 1080, 1599, 2007)), own)
+    compare_rows(r, port, sc, seeds, mine, "entities 4K share 5/8")
+    mask = np.ones(sc.width * sc.height, bool)
+    mask[own] = False
+    assert not r.read().reshape(-1, 3)[mask].any()
+    r.close()
+    loader.close()
+
+
 def test_entity_trace_records(gpu_instance, port, entity_world):
     """Every closestIntersect of one sample on ~100 pixels of the 100 k-triangle world: hit flags and block indices exact,
     every float field bit-identical (octree + world BVH + actor BVH, main and shadow traces)."""

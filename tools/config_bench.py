@@ -29,7 +29,7 @@ def run(sc, name, passes=32, launches=3, world=1, ext=None, check_rows=(60, 250,
     loader.load_packed(sc)
     r = HipPathTracingRenderer(loader, sc.width, sc.height)
     r.set_camera(sc.projector_type, sc.camera)
-    r.set_shard(0, world, 256)
+    r.set_shard(0, world, 0)   # 16 x 16-pixel blocks, as bench.py --gpus N
     for k, v in (ext or {}).items():
         r.set_option({"nee": native.OPT_EMITTER_NEE, "bsdf": native.OPT_BSDF}[k], v)
     seeds = native.java_random_ints(passes * (launches + 1))
@@ -48,7 +48,7 @@ def run(sc, name, passes=32, launches=3, world=1, ext=None, check_rows=(60, 250,
     got = r.read().reshape(-1, 3)
     rows = [min(y * sc.height // 1080, sc.height - 1) for y in check_rows]
     gids = np.concatenate([np.arange(y * sc.width, (y + 1) * sc.width) for y in rows]).astype(np.int32)
-    gids = np.intersect1d(gids, parallel.owned_gids(sc.width * sc.height, 0, world, 256)).astype(np.int32)
+    gids = np.intersect1d(gids, parallel.owned_gids(sc.width * sc.height, 0, world, 0, sc.width)).astype(np.int32)
     port = binding.port()
     port.counters(enable=True, reset=True)
     port.counters(reset=True)
@@ -59,7 +59,7 @@ def run(sc, name, passes=32, launches=3, world=1, ext=None, check_rows=(60, 250,
         want = port.render_gids(sc, seeds[:passes], gids, threads=os.cpu_count()).reshape(-1, 3)
     bps = binding.algorithmic_bytes(port.counters(enable=False, reset=True))
     same = bool(np.array_equal(got[gids].view(np.uint32), want[gids].view(np.uint32)))
-    n_local = min(parallel.local_slots(sc.width * sc.height, 0, world, 256), sc.width * sc.height)
+    n_local = int(parallel.owned_gids(sc.width * sc.height, 0, world, 0, sc.width).size)
     out = {"config": name, "scene": sc.name, "size": [sc.width, sc.height], "share": f"1/{world}", "passes_per_launch": passes,
            "kernel": info, "Msamples/s": n_local * passes * launches / dt / 1e6, "launch_ms": ms / n,
            "rows_bit_identical_to_oracle": same, "pixels_checked": int(gids.size), "algorithmic_bytes_per_sample": bps}
