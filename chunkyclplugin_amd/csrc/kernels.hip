@@ -2003,6 +2003,9 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
 
 // The running mean of K/rayTracer.cl:109-112 over the staged samples of a launch, strictly in pass order: one thread per
 // pixel and channel, reads coalesced across pixels ([pass][slot][3]).
+#ifndef CHUNKY_FOLD_NT
+#define CHUNKY_FOLD_NT 0  // with small sub-blocks a thread's consecutive passes share cache lines: plain loads keep them
+#endif
 __global__ void __launch_bounds__(256) fold_kernel(const float* __restrict__ staging, float* __restrict__ res, ShardView T, int n_pixels,
                                                     int width, long long n_slots, int n_passes, int first_spp) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -2017,7 +2020,7 @@ __global__ void __launch_bounds__(256) fold_kernel(const float* __restrict__ sta
 #pragma unroll 8
     for (int k = 0; k < n_passes; k++) {
         const int spp = first_spp + k;
-#if CHUNKY_NT
+#if CHUNKY_NT && CHUNKY_FOLD_NT
         mean = (mean * (float)spp + __builtin_nontemporal_load(p + (size_t)k * (3 * kSubBlock))) / (float)(spp + 1);
 #else
         mean = (mean * (float)spp + p[(size_t)k * (3 * kSubBlock)]) / (float)(spp + 1);
