@@ -1615,7 +1615,10 @@ constexpr int kPoolPark = CHUNKY_POOL_PARK;
 #endif
 constexpr int kModelBatch = CHUNKY_MODEL_BATCH;  // model-block candidates that share one execution of their phase
 constexpr int kPoolRefill = CHUNKY_POOL_REFILL;  // leave the march loop to refill once this many lanes are free and parked marchers exist
-constexpr int kSampleBatch = 256;                // sample indices a wave claims per atomic (measured: 64 -20 %, 128 -4 %, 512 -0.5 %, 1024 -3 %)
+#ifndef CHUNKY_SAMPLE_BATCH
+#define CHUNKY_SAMPLE_BATCH 256
+#endif
+constexpr int kSampleBatch = CHUNKY_SAMPLE_BATCH;  // sample indices a wave claims per atomic (measured: 64 -20 %, 128 -5 %, 512 -0.1 %, 1024 -1.3 %)
 
 // Samples are handed out per XCD.  Each of the eight XCDs has its own L2, and workgroup b of a launch runs on XCD b % 8 (read
 // from the hardware: HW_REG_XCC_ID).  The launch's samples — tile-major, so a contiguous range is a stripe of the image with
