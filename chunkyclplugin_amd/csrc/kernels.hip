@@ -1,8 +1,10 @@
 // kernels.hip — gfx950 kernels of the Chunky path tracer and their launchers.
 //
-// render_waves (the default): a persistent grid whose waves run the path state machine phase by phase, voted per
-// wave (MARCH / BLOCK / SHADE, plus BVH / LEAF for scenes with entities), with pixels shared by groups of lanes;
-// DESIGN.md section 5 describes it.  filter_kernel: the tone-map kernel of tonemap/include/post_processing_filter.cl.
+// render_pool (the default) + fold_kernel: a persistent grid whose waves each run a pool of 64 + K path state machines phase
+// by phase (MARCH / BLOCK / SHADE, plus the entity-BVH walk), voted over the pool, samples claimed per XCD, the running mean
+// folded afterwards in pass order; DESIGN.md section 5 describes it.  render_waves: round 1's kernel (paths bound to lanes,
+// pixels shared by groups of lanes; CHUNKY_OPT_KERNEL bit 3, and the fallback where render_pool does not apply).
+// filter_kernel: the tone-map kernel of tonemap/include/post_processing_filter.cl.
 // render_lanes: one lane owns one pixel for all the passes of a launch (the running mean of
 // K/rayTracer.cl:109-112 stays in registers: 1 framebuffer read + 1 write per launch instead of per
 // pass, same float recurrence in the same order), walking the path of K/rayTracer.cl:93-107.
@@ -1360,7 +1362,7 @@ enum : int {
 };
 
 struct PoolLds {
-    uint4* park;  // [8][K]: dword group g of slot s at park[g * K + s] (consecutive lanes, consecutive 16 bytes)
+    uint4* park;  // [WORDS][K]: 16-byte word g of slot s at park[g * K + s] (consecutive lanes, consecutive 16 bytes)
     int* tags;    // [K] state of the path parked in slot s
     int* list;    // [K] scratch: the slots taking part in a swap, by rank
 };
@@ -2338,7 +2340,7 @@ static size_t stack_lds_bytes(const SceneView& S, int block) {
     return need ? (size_t)entries * block * sizeof(int) : 0;
 }
 
-// render_pool + fold_kernel.  variant bits 6-7 pick the parked paths per wave: 0 = 48 (default), 1 = none, 2 = 32, 3 = 64.
+// render_pool + fold_kernel.  variant bits 6-7 pick the parked paths per wave: 0 = 56 (default), 1 = none, 2 = 32, 3 = 64.
 static hipError_t launch_pool(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                               const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
                               float* staging) {

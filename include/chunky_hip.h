@@ -103,7 +103,7 @@ typedef enum chunky_option {
     CHUNKY_OPT_KERNEL = 3,          /* int: kernel variant, 0 = default; bit 0 reference octree layout, bit 1 one lane
                                      * per path, bit 2 phase profile, bit 3 the grouped kernel instead of the pool kernel,
                                      * bits 4-5 (grouped kernel) lanes per pixel 1/8/16, bits 6-7 (pool kernel) paths parked
-                                     * per wave none/32/64 instead of 48 (all bit-identical) */
+                                     * per wave none/32/64 instead of 56 (all bit-identical) */
     /* EXPERIMENTAL light-transport extensions (the reference has none of them — it gates sun
      * sampling on drawTexture, PackedSun.java:16 / K/sky.h:69, ignores emittersEnabled, and loads material word 5 without
      * using it, K/material.h:38).  Specification: oracle/port.c trace_sample_ext; DESIGN.md section 9.  The defaults are the
