@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the path-tracing hot path on BASELINE.json's headline workload.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts one child process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (config.workload): BASELINE.json configs[2] — the synthetic 32x32-chunk outdoor world at
@@ -84,14 +84,19 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="rig: render only rank 0's share of an N-GPU split on one GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rigs")
     ap.add_argument("--one-device", action="store_true", help="rig: every rank uses GPU 0 (1-GPU box, with --backend gloo)")
+    ap.add_argument("--spawn", action="store_true", help="run even N = 1 as a child rank through the self-spawn path (rig)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if (args.gpus > 1 or args.spawn) and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (numpy only so far) and never will — it
+        # starts one CHILD per GPU with the torch.distributed environment, relays rank 0's JSON line and exits with the
+        # children's code.  (Under torch.distributed.run RANK is set and this branch is not taken.)
+        from chunkyclplugin_amd import parallel
+        sys.exit(parallel.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
     import torch
@@ -157,6 +162,11 @@ def main():
     kernel_ms, launches = r.kernel_time()
     info = r.kernel_info()
     per_rank = None
+    devices_seen = [local_rank]
+    if world > 1:
+        objs = [None] * world
+        dist.all_gather_object(objs, (local_rank, torch.cuda.get_device_name(local_rank)))
+        devices_seen = [o[0] for o in objs]
     if world > 1:
         mine = torch.tensor([kernel_ms, reduce_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         gathered = [torch.zeros_like(mine) for _ in range(world)]
@@ -225,6 +235,12 @@ def main():
         if args.emulate_world:
             out["emulated_world"] = args.emulate_world
             out["metric"] += f" — EMULATED rank-0 share of a {args.emulate_world}-GPU split on one GPU (not a multi-GPU result)"
+        # what the collective actually ran on: the backend and world size torch.distributed reports ("nccl" IS RCCL on ROCm)
+        out["rccl_ranks"] = dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)
+        out["collective"] = {"backend": dist.get_backend() if world > 1 else None, "ranks": dist.get_world_size() if world > 1 else 1,
+                             "devices": sorted(set(devices_seen)),
+                             "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                                         ("bench.py self-spawn" if "RANK" in os.environ else "none")}
         if per_rank:
             out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu and not args.no_roofline:

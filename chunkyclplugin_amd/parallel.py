@@ -58,3 +58,54 @@ def reduce_framebuffer(fb, dst: int = 0):
         else:
             dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb
+
+
+def spawn_ranks(script: str, argv, world: int, timeout: float | None = None) -> int:
+    """Start `world` copies of `script argv...` as CHILD processes, one per GPU, with the torch.distributed
+    environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), relay rank 0's stdout
+    and return the worst exit code.  The caller must not have touched the GPU: nothing is exec'ed in place —
+    the parent only waits (a process that has initialised HIP must never be replaced by another program).
+    If a rank fails, the others are terminated by their own PIDs (never by pattern)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    import time
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs, rc = [], 0
+    with tempfile.TemporaryFile("w+") as out0:
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.setdefault("OMP_NUM_THREADS", str(max((os.cpu_count() or world) // world, 1)))
+            procs.append(subprocess.Popen([sys.executable, script, *argv], env=env,
+                                          stdout=out0 if rank == 0 else subprocess.DEVNULL))
+        t0 = time.monotonic()
+        try:
+            while any(p.poll() is None for p in procs):
+                if any(p.poll() not in (None, 0) for p in procs):
+                    break  # a rank failed: the others would wait for it in a collective
+                if timeout is not None and time.monotonic() - t0 > timeout:
+                    rc = 124
+                    break
+                time.sleep(0.05)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        for p in procs:
+            rc = rc or (p.returncode or 0)
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    return rc

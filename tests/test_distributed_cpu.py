@@ -75,3 +75,16 @@ def test_blocks_partition_the_image(world, width, height):
             b = (g // width // 16) * ((width + 15) // 16) + (g % width) // 16
             assert (b % world == r).all()
     assert (seen == 1).all()
+
+
+def test_spawn_ranks_relays_rank0_and_exit_codes(capfd):
+    """`python bench.py --gpus N` without a launcher: parallel.spawn_ranks starts N children with the torch.distributed
+    environment, relays rank 0's line and reports failure without hanging when one rank dies."""
+    import json
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "spawn_child.py")
+    assert parallel.spawn_ranks(child, [], 3, timeout=120) == 0
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    msg = json.loads(lines[0])
+    assert msg == {"world": 3, "sum": 3.0, "local_rank": "0", "master": "127.0.0.1"}
+    assert parallel.spawn_ranks(child, ["fail"], 2, timeout=120) != 0

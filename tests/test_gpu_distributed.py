@@ -30,9 +30,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_bench(world, dump, extra=()):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
+def _run_bench(world, dump, extra=(), launcher=True):
+    launch = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] if launcher else [sys.executable])
+    cmd = [*launch, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
            "--passes", str(PASSES), "--width", str(W), "--height", str(H), "--chunks", str(CHUNKS), "--one-device", "--backend", "gloo",
            "--no-cpu", "--dump", dump, *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
@@ -71,3 +72,23 @@ def test_ranks_on_one_device_reduce_to_the_single_rank_image(tmp_path, port, sin
     gids = np.concatenate([np.arange(y * W, (y + 1) * W) for y in rows]).astype(np.int32)
     ref = port.render_gids(sc, native.java_random_ints(PASSES), gids, threads=os.cpu_count() or 8).reshape(-1, 3)[gids]
     np.testing.assert_array_equal(got.reshape(-1, 3)[gids].view(np.uint32), ref.view(np.uint32))
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path, single_rank_image):
+    """`python bench.py --gpus 2` as the driver may call it: the parent never touches the GPU, starts two child ranks itself
+    and relays rank 0's one JSON line; the reduced image is the single-process image."""
+    _sc, want = single_rank_image
+    dump = str(tmp_path / "fb_self.npy")
+    line = _run_bench(2, dump, launcher=False)
+    assert line["n_gpus"] == 2 and line["collective"] == {"backend": "gloo", "ranks": 2, "devices": [0], "launcher": "bench.py self-spawn"}
+    assert line["rccl_ranks"] == 0  # gloo rig: no RCCL ranks claimed
+    np.testing.assert_array_equal(np.load(dump).view(np.uint32), want.view(np.uint32))
+
+
+def test_single_rank_through_the_spawn_path(tmp_path, single_rank_image):
+    """N = 1 as a child rank (--spawn): same image, and the line says one rank and no collective."""
+    _sc, want = single_rank_image
+    dump = str(tmp_path / "fb_one.npy")
+    line = _run_bench(1, dump, extra=("--spawn",), launcher=False)
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["collective"]["launcher"] == "bench.py self-spawn"
+    np.testing.assert_array_equal(np.load(dump).view(np.uint32), want.view(np.uint32))
