@@ -184,9 +184,11 @@ def main():
         value = samples / dt / 1e6
         # ---- roofline: algorithmic bytes of the reference access stream on this view ---------------
         threads = os.cpu_count() or 1
-        passes_per_launch = min(args.passes, 256)
+        # what a launch really carried: chunky_render_passes cuts a step into launches of at most info["passes_per_launch"]
+        # passes (256 unless the staged samples would not fit); the timed region's samples over its launches is exact either way
         launch_ms = kernel_ms / max(launches, 1)
-        samples_per_launch = min(local_slots, n_pix) * passes_per_launch
+        samples_per_launch = min(local_slots, n_pix) * args.steps * args.passes // max(launches, 1)
+        passes_per_launch = min(args.passes, info["passes_per_launch"])
         bytes_per_sample, n_s, rows = None, 0, []
         if not args.no_roofline:
             from oracle import binding

@@ -49,6 +49,8 @@ struct chunky_ctx {
     std::recursive_mutex mu;  // the reference's renderLock
     std::string name;
     void* gamma_table = nullptr;  // 256 floats: the byte thresholds of the GAMMA / ACES tone maps (gamma_thresholds)
+    // chunky_group_create: one member context per GPU; this object then only carries the lock and fans calls out
+    std::vector<chunky_ctx*> members;
 };
 
 struct DevBuf {
@@ -98,6 +100,7 @@ struct chunky_scene {
     bool have_world = false, have_actor = false;
     int world_height = 0, actor_height = 0;  // inner-node levels: bounds the to-visit stack (K/bvh.h:38 uses 64)
     int refs = 1;  // owner + render targets
+    std::vector<chunky_scene*> replicas;  // on a group: the scene's copy on every member (this object holds no data)
 };
 
 struct chunky_render {
@@ -118,6 +121,12 @@ struct chunky_render {
     float timed_ms = 0;
     int timed_launches = 0;
     KernelChoice last_choice{0, 0, 0, 0, -1, 0};  // what the most recent launch ran (chunky_render_kernel_info)
+    int launch_cap = 0;  // most passes one launch carries here (staging size); 0 = not determined yet
+    // on a group: one target per member (this object holds no device data), the caller's share of the image, and the buffers
+    // of the read-back exchange: gather_send[i] on member i's device, gather_recv[i] on member 0's
+    std::vector<chunky_render*> parts;
+    ShardView outer{0, 1, 0, 0};
+    std::vector<DevBuf> gather_send, gather_recv;
     ~chunky_render() {
         for (auto& p : pending) {
             (void)hipEventDestroy(p.first);
@@ -177,8 +186,54 @@ extern "C" int chunky_init(int device, chunky_ctx** out) {
     return CHUNKY_OK;
 }
 
+extern "C" int chunky_group_create(const int* devices, int n, chunky_ctx** out) {
+    if (!out) return fail(CHUNKY_E_INVALID, "chunky_group_create: out is NULL");
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) return fail(CHUNKY_E_INVALID, "chunky_group_create: 1..64 devices");
+    std::unique_ptr<chunky_ctx> g(new chunky_ctx);
+    for (int i = 0; i < n; i++) {
+        chunky_ctx* m = nullptr;
+        if (int rc = chunky_init(devices[i], &m)) {
+            const std::string why = tls_error;
+            for (chunky_ctx* c : g->members) (void)chunky_shutdown(c);
+            return fail(rc, "chunky_group_create: member %d: %s", i, why.c_str());
+        }
+        g->members.push_back(m);
+    }
+    g->device = g->members[0]->device;
+    g->name = g->members[0]->name;
+    // the read-back exchange copies member i's blocks into member 0's memory: direct (xGMI) where peer access exists, staged
+    // by the runtime where it does not — failing to enable it is not an error
+    for (int i = 1; i < n; i++) {
+        if (devices[i] == devices[0]) continue;
+        int can = 0;
+        if (hipSetDevice(devices[i]) == hipSuccess && hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can)
+            (void)hipDeviceEnablePeerAccess(devices[0], 0);
+        (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled is fine
+    }
+    *out = g.release();
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_group_size(chunky_ctx* ctx) {
+    if (!ctx) return fail(CHUNKY_E_INVALID, "chunky_group_size: NULL context");
+    return ctx->members.empty() ? 1 : (int)ctx->members.size();
+}
+
+extern "C" int chunky_group_device(chunky_ctx* ctx, int i) {
+    if (!ctx || i < 0 || i >= chunky_group_size(ctx)) return fail(CHUNKY_E_INVALID, "chunky_group_device: no member %d", i);
+    return ctx->members.empty() ? ctx->device : ctx->members[(size_t)i]->device;
+}
+
 extern "C" int chunky_shutdown(chunky_ctx* ctx) {
     if (!ctx) return fail(CHUNKY_E_INVALID, "chunky_shutdown: NULL context");
+    if (!ctx->members.empty()) {
+        int rc = CHUNKY_OK;
+        for (chunky_ctx* m : ctx->members)
+            if (int e = chunky_shutdown(m)) rc = e;
+        delete ctx;
+        return rc;
+    }
     {
         std::lock_guard<std::recursive_mutex> g(ctx->mu);
         (void)hipSetDevice(ctx->device);
@@ -198,17 +253,45 @@ extern "C" int chunky_shutdown(chunky_ctx* ctx) {
 
 extern "C" int chunky_scene_create(chunky_ctx* ctx, chunky_scene** out) {
     if (!ctx || !out) return fail(CHUNKY_E_INVALID, "chunky_scene_create: NULL argument");
-    chunky_scene* s = new chunky_scene;
+    std::unique_ptr<chunky_scene> s(new chunky_scene);
     s->ctx = ctx;
-    *out = s;
+    for (chunky_ctx* m : ctx->members) {  // a group: one replica per member
+        chunky_scene* rep = nullptr;
+        if (int rc = chunky_scene_create(m, &rep)) {
+            for (chunky_scene* r : s->replicas) (void)chunky_scene_destroy(r);
+            return rc;
+        }
+        s->replicas.push_back(rep);
+    }
+    *out = s.release();
     return CHUNKY_OK;
 }
+
+// A call on a group's scene is the same call on every replica (under the group's lock: the reference's renderLock).
+template <class F>
+static int each_replica(chunky_scene* s, F call) {
+    std::lock_guard<std::recursive_mutex> g(s->ctx->mu);
+    for (chunky_scene* m : s->replicas)
+        if (int rc = call(m)) return rc;
+    return CHUNKY_OK;
+}
+#define FAN_SCENE(s, expr) \
+    if ((s) && !(s)->replicas.empty()) return each_replica((s), [&](chunky_scene* m_) { return expr; })
 
 static void scene_unref(chunky_scene* s) {
     if (--s->refs == 0) delete s;
 }
 
 extern "C" int chunky_scene_destroy(chunky_scene* scene) {
+    if (scene && !scene->replicas.empty()) {
+        const int rc = each_replica(scene, [&](chunky_scene* m_) { return chunky_scene_destroy(m_); });
+        {
+            std::lock_guard<std::recursive_mutex> g(scene->ctx->mu);
+            scene->replicas.clear();
+        }
+        scene_unref(scene);
+        return rc;
+    }
     LOCK_SCENE(scene);
     (void)hipStreamSynchronize(scene->ctx->stream);
     scene_unref(scene);
@@ -221,6 +304,7 @@ static int check_ints(const int32_t* p, int64_t n, const char* what) {
 }
 
 extern "C" int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree, int64_t n, int depth) {
+    FAN_SCENE(scene, chunky_scene_set_octree(m_, tree, n, depth));
     LOCK_SCENE(scene);
     if (int rc = check_ints(tree, n, "set_octree")) return rc;
     if (n < 1) return fail(CHUNKY_E_INVALID, "set_octree: empty tree");
@@ -269,6 +353,7 @@ extern "C" int chunky_scene_load_octree(chunky_scene* scene, const int32_t* tree
 }
 
 extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int32_t* data, int64_t n) {
+    FAN_SCENE(scene, chunky_scene_set_palette(m_, kind, data, n));
     LOCK_SCENE(scene);
     if (int rc = check_ints(data, n, "set_palette")) return rc;
     DevBuf* dst = nullptr;
@@ -296,6 +381,7 @@ extern "C" int chunky_scene_set_palette(chunky_scene* scene, int kind, const int
 }
 
 extern "C" int chunky_scene_set_bvh(chunky_scene* scene, int which, const int32_t* nodes, int64_t n) {
+    FAN_SCENE(scene, chunky_scene_set_bvh(m_, which, nodes, n));
     LOCK_SCENE(scene);
     if (int rc = check_ints(nodes, n, "set_bvh")) return rc;
     if (which != CHUNKY_BVH_WORLD && which != CHUNKY_BVH_ACTOR) return fail(CHUNKY_E_INVALID, "set_bvh: which=%d", which);
@@ -342,6 +428,7 @@ extern "C" int chunky_scene_set_bvh(chunky_scene* scene, int which, const int32_
 }
 
 extern "C" int chunky_scene_set_atlas(chunky_scene* scene, const uint8_t* rgba, int w, int h, int layers) {
+    FAN_SCENE(scene, chunky_scene_set_atlas(m_, rgba, w, h, layers));
     LOCK_SCENE(scene);
     if (w <= 0 || h <= 0 || layers <= 0) return fail(CHUNKY_E_INVALID, "set_atlas: bad size %dx%dx%d", w, h, layers);
     size_t bytes = (size_t)w * h * layers * 4;
@@ -362,6 +449,7 @@ extern "C" int chunky_scene_set_atlas(chunky_scene* scene, const uint8_t* rgba, 
 
 extern "C" int chunky_scene_write_atlas_tile(chunky_scene* scene, int x, int y, int layer, int w, int h,
                                              const uint8_t* rgba) {
+    FAN_SCENE(scene, chunky_scene_write_atlas_tile(m_, x, y, layer, w, h, rgba));
     LOCK_SCENE(scene);
     if (!scene->atlas.p) return fail(CHUNKY_E_STATE, "write_atlas_tile before set_atlas");
     if (!rgba || x < 0 || y < 0 || layer < 0 || w <= 0 || h <= 0 || x + w > scene->atlas_w || y + h > scene->atlas_h ||
@@ -375,6 +463,7 @@ extern "C" int chunky_scene_write_atlas_tile(chunky_scene* scene, int x, int y, 
 }
 
 extern "C" int chunky_scene_set_sky(chunky_scene* scene, const uint8_t* rgba, int w, int h, float intensity) {
+    FAN_SCENE(scene, chunky_scene_set_sky(m_, rgba, w, h, intensity));
     LOCK_SCENE(scene);
     if (!rgba || w <= 0 || h <= 0) return fail(CHUNKY_E_INVALID, "set_sky: bad texture");
     // texels are converted once here with the same rt_unorm8 the kernels would apply per sample
@@ -388,23 +477,30 @@ extern "C" int chunky_scene_set_sky(chunky_scene* scene, const uint8_t* rgba, in
 }
 
 static void list_emitters(const chunky_scene* s, std::vector<int32_t>* out);
+// The emitter list exists only for CHUNKY_OPT_EMITTER_NEE and chunky_scene_emitters: built on first use after a change.
+static int refresh_emitters(chunky_scene* s) {
+    if (!s->emitters_dirty) return CHUNKY_OK;
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));  // queued passes may still read the old list
+    list_emitters(s, &s->host_emitters);
+    s->emitters.release();
+    if (!s->host_emitters.empty()) HIP_TRY(s->emitters.upload(s->host_emitters.data(), s->host_emitters.size() * 4, s->ctx->stream));
+    s->emitters_dirty = false;
+    return CHUNKY_OK;
+}
 extern "C" int chunky_scene_emitters(chunky_scene* scene, int32_t* out4, int32_t cap, int32_t* count) {
+    if (scene && !scene->replicas.empty()) return chunky_scene_emitters(scene->replicas[0], out4, cap, count);  // replicas agree
     LOCK_SCENE(scene);
     if (!count || cap < 0 || (cap > 0 && !out4)) return fail(CHUNKY_E_INVALID, "scene_emitters: bad arguments");
-    if (scene->emitters_dirty) {
-        list_emitters(scene, &scene->host_emitters);
-        HIP_TRY(hipStreamSynchronize(scene->ctx->stream));
-        scene->emitters.release();
-        if (!scene->host_emitters.empty()) HIP_TRY(scene->emitters.upload(scene->host_emitters.data(), scene->host_emitters.size() * 4, scene->ctx->stream));
-        scene->emitters_dirty = false;
-    }
+    if (int rc = refresh_emitters(scene)) return rc;
     const int32_t n = (int32_t)(scene->host_emitters.size() / 4);
     *count = n;
-    memcpy(out4, scene->host_emitters.data(), (size_t)(n < cap ? n : cap) * 16);
+    const int32_t give = n < cap ? n : cap;
+    if (out4 && give > 0) memcpy(out4, scene->host_emitters.data(), (size_t)give * 16);
     return CHUNKY_OK;
 }
 
 extern "C" int chunky_scene_set_sun(chunky_scene* scene, const int32_t sun[6]) {
+    FAN_SCENE(scene, chunky_scene_set_sun(m_, sun));
     LOCK_SCENE(scene);
     if (!sun) return fail(CHUNKY_E_INVALID, "set_sun: NULL");
     memcpy(scene->sun, sun, sizeof scene->sun);
@@ -675,16 +771,22 @@ static void list_emitters(const chunky_scene* s, std::vector<int32_t>* out) {
     if (T.empty() || s->octree_depth < 0 || s->octree_depth > 15) return;
     struct Item { int64_t node; int x, y, z, level; };
     std::vector<Item> todo{{0, 0, 0, 0, s->octree_depth}};
+    // chunky_scene_set_octree only checks that branch values stay inside the array: a tree with a cycle, or with branches
+    // below level 0, must not make this walk run or allocate without end — the kernels' walk is bounded by the depth, so
+    // here a node at level 0 is a leaf whatever it holds, and no more nodes are visited than the array has
+    size_t visited = 0;
     while (!todo.empty()) {
         const Item it = todo.back();
         todo.pop_back();
+        if (++visited > T.size()) break;
         const int32_t v = T[(size_t)it.node];
-        if (v > 0) {
+        if (v > 0 && it.level > 0) {
             const int h = 1 << (it.level - 1);
             for (int c = 7; c >= 0; c--)  // pushed in reverse: popped in index order
                 todo.push_back({(int64_t)v + c, it.x + ((c >> 2) & 1) * h, it.y + ((c >> 1) & 1) * h, it.z + (c & 1) * h, it.level - 1});
             continue;
         }
+        if (v > 0) continue;  // a branch below level 0: not a leaf the kernels can reach
         const int64_t block = -(int64_t)v;
         if (block == 0 || block == 0x7FFFFFFE || block + 1 >= (int64_t)B.size() || block >= (1 << 25)) continue;
         if (B[(size_t)block] != 1) continue;
@@ -698,7 +800,7 @@ static void list_emitters(const chunky_scene* s, std::vector<int32_t>* out) {
 
 // Assemble the kernel-side view; Sun_new (K/sky.h:19-40) is evaluated here, on the host, with the
 // same rt_math.h the device uses.
-static int scene_view(chunky_scene* s, SceneView* v) {
+static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false) {
     if (!s->octree.p || s->octree_depth < 0) return fail(CHUNKY_E_STATE, "scene has no octree");
     if (!s->blocks.p || !s->materials.p) return fail(CHUNKY_E_STATE, "scene has no block/material palette");
     if (!s->atlas.p) return fail(CHUNKY_E_STATE, "scene has no texture atlas");
@@ -765,15 +867,10 @@ static int scene_view(chunky_scene* s, SceneView* v) {
         }
         s->bvh_dirty = false;
     }
-    if (s->emitters_dirty) {
-        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-        list_emitters(s, &s->host_emitters);
-        s->emitters.release();
-        if (!s->host_emitters.empty()) HIP_TRY(s->emitters.upload(s->host_emitters.data(), s->host_emitters.size() * 4, s->ctx->stream));
-        s->emitters_dirty = false;
-    }
-    v->emitters = (const int4*)s->emitters.p;
-    v->n_emitters = (int)(s->host_emitters.size() / 4);
+    if (want_emitters)
+        if (int rc = refresh_emitters(s)) return rc;
+    v->emitters = want_emitters ? (const int4*)s->emitters.p : nullptr;
+    v->n_emitters = want_emitters ? (int)(s->host_emitters.size() / 4) : 0;
     v->bvh_rec = (const int4*)s->bvh_rec.p;
     v->tri_rec = (const int4*)s->tri_rec.p;
     v->world_root = s->world_root;
@@ -800,11 +897,54 @@ static int scene_view(chunky_scene* s, SceneView* v) {
     std::lock_guard<std::recursive_mutex> guard_((r)->ctx->mu);              \
     HIP_TRY(hipSetDevice((r)->ctx->device))
 
+// A call on a group's render target is the same call on every member's part.
+template <class F>
+static int each_part(chunky_render* r, F call) {
+    std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
+    for (chunky_render* m : r->parts)
+        if (int rc = call(m)) return rc;
+    return CHUNKY_OK;
+}
+#define FAN_RENDER(r, expr) \
+    if ((r) && !(r)->parts.empty()) return each_part((r), [&](chunky_render* m_) { return expr; })
+
+// member i of n renders rank * n + i of world * n of the image (rank / world: the caller's own share, chunky_render_set_shard)
+static int group_apply_shards(chunky_render* r) {
+    const int n = (int)r->parts.size();
+    for (int i = 0; i < n; i++)
+        if (int rc = chunky_render_set_shard(r->parts[(size_t)i], r->outer.rank * n + i, r->outer.world * n, r->outer.tile)) return rc;
+    return CHUNKY_OK;
+}
+
 extern "C" int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int width, int height, chunky_render** out) {
     if (!ctx || !scene || !out) return fail(CHUNKY_E_INVALID, "chunky_render_create: NULL argument");
     if (scene->ctx != ctx) return fail(CHUNKY_E_INVALID, "scene belongs to another context");
     if (width <= 0 || height <= 0 || (int64_t)width * height > (1 << 30))
         return fail(CHUNKY_E_INVALID, "bad image size %dx%d", width, height);
+    if (!ctx->members.empty()) {
+        std::lock_guard<std::recursive_mutex> g(ctx->mu);
+        std::unique_ptr<chunky_render> r(new chunky_render);
+        r->ctx = ctx;
+        r->scene = scene;
+        r->width = width;
+        r->height = height;
+        int rc = CHUNKY_OK;
+        for (size_t i = 0; i < ctx->members.size() && rc == CHUNKY_OK; i++) {
+            chunky_render* part = nullptr;
+            rc = chunky_render_create(ctx->members[i], scene->replicas[i], width, height, &part);
+            if (rc == CHUNKY_OK) r->parts.push_back(part);
+        }
+        if (rc == CHUNKY_OK) rc = group_apply_shards(r.get());
+        if (rc != CHUNKY_OK) {
+            for (chunky_render* part : r->parts) (void)chunky_render_destroy(part);
+            return rc;
+        }
+        r->gather_send.resize(ctx->members.size());
+        r->gather_recv.resize(ctx->members.size());
+        scene->refs++;
+        *out = r.release();
+        return CHUNKY_OK;
+    }
     std::lock_guard<std::recursive_mutex> g(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     std::unique_ptr<chunky_render> r(new chunky_render);
@@ -828,6 +968,21 @@ extern "C" int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int wi
 }
 
 extern "C" int chunky_render_destroy(chunky_render* r) {
+    if (r && !r->parts.empty()) {
+        int rc = each_part(r, [&](chunky_render* m_) { return chunky_render_destroy(m_); });
+        {
+            std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
+            for (size_t i = 0; i < r->gather_send.size(); i++) {  // each buffer is freed on the device it lives on
+                (void)hipSetDevice(r->ctx->members[i]->device);
+                r->gather_send[i].release();
+                (void)hipSetDevice(r->ctx->members[0]->device);
+                r->gather_recv[i].release();
+            }
+            scene_unref(r->scene);
+        }
+        delete r;
+        return rc;
+    }
     LOCK_RENDER(r);
     (void)hipStreamSynchronize(r->ctx->stream);
     scene_unref(r->scene);
@@ -836,6 +991,7 @@ extern "C" int chunky_render_destroy(chunky_render* r) {
 }
 
 extern "C" int chunky_render_set_camera(chunky_render* r, int projector_type, const float* settings, int64_t n) {
+    FAN_RENDER(r, chunky_render_set_camera(m_, projector_type, settings, n));
     LOCK_RENDER(r);
     if (!settings) return fail(CHUNKY_E_INVALID, "set_camera: NULL settings");
     CameraView& c = r->cam;
@@ -866,6 +1022,7 @@ extern "C" int chunky_render_set_camera(chunky_render* r, int projector_type, co
 }
 
 extern "C" int chunky_render_set_option(chunky_render* r, int option, int32_t value) {
+    FAN_RENDER(r, chunky_render_set_option(m_, option, value));
     LOCK_RENDER(r);
     switch (option) {
         case CHUNKY_OPT_DRAW_DEPTH:
@@ -900,15 +1057,23 @@ extern "C" int chunky_render_set_option(chunky_render* r, int option, int32_t va
 }
 
 extern "C" int chunky_render_set_shard(chunky_render* r, int rank, int world, int tile) {
+    if (r && !r->parts.empty()) {
+        if (world < 1 || rank < 0 || rank >= world || tile < 0) return fail(CHUNKY_E_INVALID, "set_shard: rank %d / world %d / tile %d", rank, world, tile);
+        std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
+        r->outer = ShardView{rank, world, tile, 0};
+        return group_apply_shards(r);
+    }
     LOCK_RENDER(r);
     if (world < 1 || rank < 0 || rank >= world || tile < 0) return fail(CHUNKY_E_INVALID, "set_shard: rank %d / world %d / tile %d", rank, world, tile);
     ShardView t{rank, world, tile, 0};
     t.n_local = n_local_slots(r->width, r->height, t);
     r->shard = t;
+    r->launch_cap = 0;  // the share changed: so does what a launch can stage
     return CHUNKY_OK;
 }
 
 extern "C" int chunky_render_set_device_buffer(chunky_render* r, void* device_ptr) {
+    if (r && !r->parts.empty()) return chunky_render_set_device_buffer(r->parts[0], device_ptr);  // the image lives on member 0
     LOCK_RENDER(r);
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
     r->fb = device_ptr ? (float*)device_ptr : (float*)r->own_fb.p;
@@ -916,6 +1081,7 @@ extern "C" int chunky_render_set_device_buffer(chunky_render* r, void* device_pt
 }
 
 extern "C" int chunky_render_device_buffer(chunky_render* r, void** device_ptr) {
+    if (r && !r->parts.empty()) return chunky_render_device_buffer(r->parts[0], device_ptr);
     LOCK_RENDER(r);
     if (!device_ptr) return fail(CHUNKY_E_INVALID, "NULL out pointer");
     *device_ptr = r->fb;
@@ -923,6 +1089,7 @@ extern "C" int chunky_render_device_buffer(chunky_render* r, void** device_ptr) 
 }
 
 extern "C" int chunky_render_reset(chunky_render* r) {
+    FAN_RENDER(r, chunky_render_reset(m_));
     LOCK_RENDER(r);
     HIP_TRY(hipMemsetAsync(r->fb, 0, (size_t)r->width * r->height * 3 * sizeof(float), r->ctx->stream));
     return CHUNKY_OK;
@@ -951,12 +1118,25 @@ static int collect_timing(chunky_render* r) {
     return CHUNKY_OK;
 }
 
+// The most passes one launch of this target carries: render_pool stages every sample of a launch (12 bytes each) — at most
+// kStagingBytes of it, fewer than 2^31 samples, at most kMaxPassesPerLaunch passes.  Sized by the tiles THIS rank renders.
+static int launch_pass_cap(const chunky_render* r, size_t budget) {
+    const int64_t n_slots = (int64_t)(staging_floats(r->shard, r->width, r->height, 1) / 3);  // padded tiles
+    if (n_slots <= 0) return kMaxPassesPerLaunch;
+    int64_t cap = (int64_t)(budget / 12) / n_slots;
+    const int64_t cap31 = ((int64_t)1 << 31) / n_slots - 1;
+    if (cap > cap31) cap = cap31;
+    if (cap > kMaxPassesPerLaunch) cap = kMaxPassesPerLaunch;
+    return cap < 1 ? 1 : (int)cap;
+}
+
 extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int n, int first_buffer_spp) {
+    FAN_RENDER(r, chunky_render_passes(m_, seeds, n, first_buffer_spp));  // asynchronous on every member: the shares run side by side
     LOCK_RENDER(r);
     if (n < 0 || (n > 0 && !seeds) || first_buffer_spp < 0) return fail(CHUNKY_E_INVALID, "render_passes: bad arguments");
     if (!r->have_camera) return fail(CHUNKY_E_STATE, "render_passes before set_camera");
     SceneView S;
-    if (int rc = scene_view(r->scene, &S)) return rc;
+    if (int rc = scene_view(r->scene, &S, r->opts.nee != 0)) return rc;
     if (opts_extended(r->opts)) {  // the extensions exist in render_pool only
         const bool bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
         if ((r->kernel_variant & (1 | 2 | 4 | 8)) || (bvh && !(S.bvh_rec && S.tri_rec && S.mat8)))
@@ -964,25 +1144,27 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
     }
     if (r->pending.size() > 4096)
         if (int rc = collect_timing(r)) return rc;
-    // render_pool stages every sample of a launch (12 bytes each): at most kStagingBytes of it, and fewer than 2^31 samples
-    const int64_t n_slots = (int64_t)(staging_floats(r->shard.n_local, r->width, r->height, 1) / 3);  // padded tiles
-    int64_t cap = (int64_t)(kStagingBytes / 12) / n_slots;
-    const int64_t cap31 = ((int64_t)1 << 31) / n_slots - 1;
-    if (cap > cap31) cap = cap31;
-    if (cap > kMaxPassesPerLaunch) cap = kMaxPassesPerLaunch;
-    if (cap < 1) cap = 1;
+    if (r->launch_cap <= 0) r->launch_cap = launch_pass_cap(r, kStagingBytes);
     for (int done = 0; done < n;) {
         PassSeeds ps;
-        ps.n = (n - done) < (int)cap ? (n - done) : (int)cap;
-        ps.first_spp = first_buffer_spp + done;
-        memcpy(ps.seed, seeds + done, (size_t)ps.n * 4);
-        const size_t need = staging_floats(r->shard.n_local, r->width, r->height, ps.n) * sizeof(float);
+        ps.n = (n - done) < r->launch_cap ? (n - done) : r->launch_cap;
+        size_t need = staging_floats(r->shard, r->width, r->height, ps.n) * sizeof(float);
         if (r->staging.bytes < need) {  // grows to the largest launch seen; launches on the stream are ordered, so it is reused
             HIP_TRY(hipStreamSynchronize(r->ctx->stream));
             r->staging.release();
-            HIP_TRY(hipMalloc(&r->staging.p, need));
+            // memory is short: shorter launches instead of a failed render (each halving halves the array)
+            while (hipMalloc(&r->staging.p, need) != hipSuccess) {
+                (void)hipGetLastError();
+                r->staging.p = nullptr;
+                if (ps.n == 1) return fail(CHUNKY_E_HIP, "render_passes: cannot allocate %zu bytes for one pass of staged samples", need);
+                ps.n = (ps.n + 1) / 2;
+                r->launch_cap = ps.n;
+                need = staging_floats(r->shard, r->width, r->height, ps.n) * sizeof(float);
+            }
             r->staging.bytes = need;
         }
+        ps.first_spp = first_buffer_spp + done;
+        memcpy(ps.seed, seeds + done, (size_t)ps.n * 4);
         hipEvent_t e0, e1;
         HIP_TRY(get_event(r, &e0));
         HIP_TRY(get_event(r, &e1));
@@ -997,12 +1179,73 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
 }
 
 extern "C" int chunky_render_sync(chunky_render* r) {
+    FAN_RENDER(r, chunky_render_sync(m_));
     LOCK_RENDER(r);
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
     return CHUNKY_OK;
 }
 
+// The one exchange per read-back of a group: every member but the first packs the pixels of the
+// blocks it owns (3 floats each, in the order of its pixel slots), copies them into member 0's memory, and member 0
+// scatters them into the image.  Blocks are disjoint, so this is the "reduce of per-tile radiance" with 1/n of the bytes
+// per member and no arithmetic: the image is bit for bit what one GPU renders.
+static int group_gather(chunky_render* r) {
+    chunky_render* p0 = r->parts[0];
+    const int dev0 = p0->ctx->device;
+    const size_t n = r->parts.size();
+    for (size_t i = 1; i < n; i++) {
+        chunky_render* pi = r->parts[i];
+        std::lock_guard<std::recursive_mutex> gi(pi->ctx->mu);
+        const size_t bytes = (size_t)pi->shard.n_local * 3 * sizeof(float);
+        if (bytes == 0) continue;
+        if (r->gather_recv[i].bytes < bytes) {
+            HIP_TRY(hipSetDevice(dev0));
+            r->gather_recv[i].release();
+            HIP_TRY(hipMalloc(&r->gather_recv[i].p, bytes));
+            r->gather_recv[i].bytes = bytes;
+        }
+        HIP_TRY(hipSetDevice(pi->ctx->device));
+        if (r->gather_send[i].bytes < bytes) {
+            r->gather_send[i].release();
+            HIP_TRY(hipMalloc(&r->gather_send[i].p, bytes));
+            r->gather_send[i].bytes = bytes;
+        }
+        // on member i's stream, behind its queued passes: pack, then the copy across
+        HIP_TRY(launch_gather(true, pi->shard, pi->width, pi->height, pi->fb, (float*)r->gather_send[i].p, pi->ctx->stream));
+        if (pi->ctx->device == dev0)
+            HIP_TRY(hipMemcpyAsync(r->gather_recv[i].p, r->gather_send[i].p, bytes, hipMemcpyDeviceToDevice, pi->ctx->stream));
+        else
+            HIP_TRY(hipMemcpyPeerAsync(r->gather_recv[i].p, dev0, r->gather_send[i].p, pi->ctx->device, bytes, pi->ctx->stream));
+    }
+    for (size_t i = 1; i < n; i++) {  // the members work side by side; the host waits for each in turn
+        HIP_TRY(hipSetDevice(r->parts[i]->ctx->device));
+        HIP_TRY(hipStreamSynchronize(r->parts[i]->ctx->stream));
+    }
+    std::lock_guard<std::recursive_mutex> g0(p0->ctx->mu);
+    HIP_TRY(hipSetDevice(dev0));
+    for (size_t i = 1; i < n; i++)
+        if (r->parts[i]->shard.n_local > 0)
+            HIP_TRY(launch_gather(false, r->parts[i]->shard, p0->width, p0->height, p0->fb, (float*)r->gather_recv[i].p, p0->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p0->ctx->stream));
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_render_gather(chunky_render* r) {
+    if (r && !r->parts.empty()) {
+        std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
+        return group_gather(r);
+    }
+    return chunky_render_sync(r);
+}
+
 extern "C" int chunky_render_read(chunky_render* r, float* out, int64_t n) {
+    if (r && !r->parts.empty()) {
+        std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
+        const int64_t need = (int64_t)r->width * r->height * 3;
+        if (!out || n != need) return fail(CHUNKY_E_INVALID, "render_read: need %lld floats, got %lld", (long long)need, (long long)n);
+        if (int rc = group_gather(r)) return rc;
+        return chunky_render_read(r->parts[0], out, n);
+    }
     LOCK_RENDER(r);
     int64_t need = (int64_t)r->width * r->height * 3;
     if (!out || n != need) return fail(CHUNKY_E_INVALID, "render_read: need %lld floats, got %lld", (long long)need, (long long)n);
@@ -1012,6 +1255,19 @@ extern "C" int chunky_render_read(chunky_render* r, float* out, int64_t n) {
 }
 
 extern "C" int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches) {
+    if (r && !r->parts.empty()) {  // the members run side by side: the slowest one's total, member 0's launch count
+        std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
+        float worst = 0;
+        for (size_t i = 0; i < r->parts.size(); i++) {
+            float ms = 0;
+            int n = 0;
+            if (int rc = chunky_render_kernel_time(r->parts[i], &ms, &n)) return rc;
+            if (ms > worst) worst = ms;
+            if (i == 0 && launches) *launches = n;
+        }
+        if (total_ms) *total_ms = worst;
+        return CHUNKY_OK;
+    }
     LOCK_RENDER(r);
     if (int rc = collect_timing(r)) return rc;
     if (total_ms) *total_ms = r->timed_ms;
@@ -1022,6 +1278,7 @@ extern "C" int chunky_render_kernel_time(chunky_render* r, float* total_ms, int*
 }
 
 extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]) {
+    if (r && !r->parts.empty()) return chunky_render_kernel_info(r->parts[0], out8);
     LOCK_RENDER(r);
     if (!out8) return fail(CHUNKY_E_INVALID, "kernel_info: NULL output");
     memset(out8, 0, 8 * sizeof(int32_t));
@@ -1031,10 +1288,12 @@ extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]) {
     out8[3] = r->last_choice.blocks;
     out8[4] = r->last_choice.pool;
     out8[5] = r->last_choice.ext;
+    out8[6] = r->launch_cap > 0 ? r->launch_cap : launch_pass_cap(r, kStagingBytes);
     return CHUNKY_OK;
 }
 
 extern "C" int chunky_render_phase_stats(chunky_render* r, uint64_t* out24, int reset) {
+    if (r && !r->parts.empty()) return chunky_render_phase_stats(r->parts[0], out24, reset);
     LOCK_RENDER(r);
     if (!out24) return fail(CHUNKY_E_INVALID, "phase_stats: NULL output");
     HIP_TRY(hipStreamSynchronize(r->ctx->stream));
@@ -1044,6 +1303,7 @@ extern "C" int chunky_render_phase_stats(chunky_render* r, uint64_t* out24, int 
 }
 
 extern "C" int chunky_render_preview(chunky_render* r, int32_t* argb_out) {
+    if (r && !r->parts.empty()) return chunky_render_preview(r->parts[0], argb_out);  // one first-hit pass of the whole image: member 0
     LOCK_RENDER(r);
     if (!argb_out) return fail(CHUNKY_E_INVALID, "preview: NULL output");
     if (!r->have_camera) return fail(CHUNKY_E_STATE, "preview before set_camera");
@@ -1061,6 +1321,7 @@ extern "C" int chunky_render_preview(chunky_render* r, int32_t* argb_out) {
 
 extern "C" int chunky_render_trace_records(chunky_render* r, int32_t seed, const int32_t* gids, int n,
                                            chunky_hit_record* records, int32_t* counts, float* radiance) {
+    if (r && !r->parts.empty()) return chunky_render_trace_records(r->parts[0], seed, gids, n, records, counts, radiance);
     LOCK_RENDER(r);
     if (n < 0 || (n > 0 && (!gids || !records || !counts || !radiance))) return fail(CHUNKY_E_INVALID, "trace_records: bad arguments");
     if (!r->have_camera) return fail(CHUNKY_E_STATE, "trace_records before set_camera");
@@ -1109,7 +1370,7 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
     if (!r || !r->ctx) return fail(CHUNKY_E_INVALID, "NULL render");
     if (!sample_buffer || !scene_spp) return fail(CHUNKY_E_INVALID, "render_run: NULL buffer");
     if (merge_interval < 1) merge_interval = 1024;  // OpenClPathTracingRenderer.java:158
-    const chunky_run_callbacks none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const chunky_run_callbacks none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const chunky_run_callbacks& cb = callbacks ? *callbacks : none;
     const int64_t n = (int64_t)r->width * r->height * 3;
     std::vector<float> pass_buffer((size_t)n);
@@ -1122,14 +1383,15 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
     while (logical_spp < target_spp) { // :102
         int buffer_spp = 0;            // bufferSppReal
         int until_merge = target_spp - logical_spp < merge_interval ? target_spp - logical_spp : merge_interval;
-        bool stop = false, save = false;
+        bool stop = false, save = false, save_poll = false;
         while (buffer_spp < until_merge && !save) {
             int m = until_merge - buffer_spp < launch_passes ? until_merge - buffer_spp : launch_passes;
-            if (cb.save_event)  // a snapshot / dump due inside the next launch ends it there (:150)
+            if (cb.save_event)  // a snapshot / dump due inside the next launch, or a buffer to finalize, ends it there (:150)
                 for (int k = 1; k <= m; k++)
-                    if (cb.save_event(cb.user, logical_spp + buffer_spp + k)) {
+                    if (const int ev = cb.save_event(cb.user, logical_spp + buffer_spp + k)) {
                         m = k;
                         save = true;
+                        save_poll = ev != 2;  // a real save event is followed by one more poll (:179-182); shouldFinalizeBuffer alone is not
                         break;
                     }
             std::vector<int32_t> seeds((size_t)m);
@@ -1145,7 +1407,8 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
             double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
             if (ms < 25.0 && launch_passes < kMaxPassesPerLaunch) launch_passes *= 2;
             if (ms > 90.0 && launch_passes > 1) launch_passes /= 2;
-            if (!save && cb.post_render && std::chrono::duration<double, std::milli>(t1 - last_callback).count() > 100.0) {  // :153-157
+            if (!save && cb.post_render && std::chrono::duration<double, std::milli>(t1 - last_callback).count() > 100.0 &&
+                (!cb.poll_gate || cb.poll_gate(cb.user))) {  // :153-157; the gate is `!manager.shouldFinalize()` (:154)
                 last_callback = t1;
                 if (cb.post_render(cb.user)) {
                     stop = true;
@@ -1164,7 +1427,7 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
         logical_spp += buffer_spp;                                            // :178
         if (cb.merged) cb.merged(cb.user, samp_spp);                          // :174-176
         if (stop) return fail(CHUNKY_E_ABORTED, "stopped by postRender");
-        if (save && cb.post_render && cb.post_render(cb.user)) return fail(CHUNKY_E_ABORTED, "stopped by postRender");  // :179-182
+        if (save_poll && cb.post_render && cb.post_render(cb.user)) return fail(CHUNKY_E_ABORTED, "stopped by postRender");  // :179-182
         // bufferSppReal = 0 (:170): the next pass runs with spp = 0, i.e. (mean*0 + c)/1 — no reset needed
     }
     return CHUNKY_OK;
@@ -1172,7 +1435,7 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
 
 extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
                                  int32_t merge_interval, chunky_post_render_fn post_render, void* user) {
-    const chunky_run_callbacks cb{post_render, nullptr, nullptr, nullptr, nullptr, user};
+    const chunky_run_callbacks cb{post_render, nullptr, nullptr, nullptr, nullptr, user, nullptr};
     return chunky_render_run_ex(r, sample_buffer, scene_spp, target_spp, merge_interval, &cb);
 }
 

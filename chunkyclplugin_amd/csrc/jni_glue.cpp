@@ -47,13 +47,13 @@ struct Ints {  // pins a Java int[] for the duration of one call (the C side cop
     ~Ints() { if (p) env->ReleaseIntArrayElements(arr, p, JNI_ABORT); }
 };
 
-// The listener of HipNative.renderRun (HipNative.RunListener): the five hooks of chunky_run_callbacks.  The loop merges
+// The listener of HipNative.renderRun (HipNative.RunListener): the six hooks of chunky_run_callbacks.  The loop merges
 // into a NATIVE buffer; before `merged` reaches Java the buffer is copied into the Java double[] (SetDoubleArrayRegion),
 // so scene.postProcessFrame sees the merged samples on copying and on pinning JVMs alike.
 struct Run {
     JNIEnv* env;
     jobject listener;
-    jmethodID post_render, progress, merged, save_event, regenerate_camera;
+    jmethodID post_render, progress, merged, save_event, regenerate_camera, poll_gate;
     jdoubleArray samples;
     std::vector<double>* buffer;
     bool failed;  // a Java exception is pending: stop the loop
@@ -84,8 +84,14 @@ void cb_merged(void* user, int32_t sample_spp) {
 int cb_save_event(void* user, int32_t spp) {
     Run* run = static_cast<Run*>(user);
     if (run->failed) return 0;
-    const bool due = run->env->CallBooleanMethod(run->listener, run->save_event, (jint)spp);
-    return (!pending(run) && due) ? 1 : 0;
+    const jint due = run->env->CallIntMethod(run->listener, run->save_event, (jint)spp);
+    return pending(run) ? 0 : (int)due;
+}
+int cb_poll_gate(void* user) {
+    Run* run = static_cast<Run*>(user);
+    if (run->failed) return 1;  // let the poll through: cb_post_render then stops the loop
+    const bool open = run->env->CallBooleanMethod(run->listener, run->poll_gate);
+    return (pending(run) || open) ? 1 : 0;
 }
 void cb_regenerate_camera(void* user) {
     Run* run = static_cast<Run*>(user);
@@ -110,6 +116,18 @@ JNIEXPORT jlong JNICALL J(init)(JNIEnv* env, jclass, jint device) {
     chunky_ctx* c = nullptr;
     if (chunky_init(device, &c) != CHUNKY_OK) throw_last(env);
     return (jlong)c;
+}
+JNIEXPORT jlong JNICALL J(groupCreate)(JNIEnv* env, jclass, jintArray devices) {
+    if (bad_length(env, devices, 1, "groupCreate")) return 0;
+    Ints d(env, devices);
+    chunky_ctx* c = nullptr;
+    if (chunky_group_create((const int*)d.p, d.n, &c) != CHUNKY_OK) throw_last(env);
+    return (jlong)c;
+}
+JNIEXPORT jint JNICALL J(groupSize)(JNIEnv* env, jclass, jlong ctx) {
+    const int n = chunky_group_size((chunky_ctx*)ctx);
+    if (n < 0) throw_last(env);
+    return n;
 }
 JNIEXPORT void JNICALL J(shutdown)(JNIEnv* env, jclass, jlong ctx) { CHECK(chunky_shutdown((chunky_ctx*)ctx)); }
 JNIEXPORT jlong JNICALL J(sceneCreate)(JNIEnv* env, jclass, jlong ctx) {
@@ -221,20 +239,22 @@ JNIEXPORT jint JNICALL J(renderRun)(JNIEnv* env, jclass, jlong r, jint width, ji
     }
     std::vector<double> buffer((size_t)3 * width * height);
     env->GetDoubleArrayRegion(samples, 0, (jsize)buffer.size(), buffer.data());
-    Run run{env, listener, nullptr, nullptr, nullptr, nullptr, nullptr, samples, &buffer, false};
-    chunky_run_callbacks cb{nullptr, nullptr, cb_merged, nullptr, nullptr, &run};
+    Run run{env, listener, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, samples, &buffer, false};
+    chunky_run_callbacks cb{nullptr, nullptr, cb_merged, nullptr, nullptr, &run, nullptr};
     if (listener) {
         jclass cls = env->GetObjectClass(listener);
         run.post_render = env->GetMethodID(cls, "postRender", "()Z");
         run.progress = env->GetMethodID(cls, "progress", "(I)V");
         run.merged = env->GetMethodID(cls, "merged", "(I)V");
-        run.save_event = env->GetMethodID(cls, "saveEvent", "(I)Z");
+        run.save_event = env->GetMethodID(cls, "saveEvent", "(I)I");
         run.regenerate_camera = env->GetMethodID(cls, "regenerateCamera", "()V");
-        if (!run.post_render || !run.progress || !run.merged || !run.save_event || !run.regenerate_camera) return sceneSpp;  // NoSuchMethodError pending
+        run.poll_gate = env->GetMethodID(cls, "pollGate", "()Z");
+        if (!run.post_render || !run.progress || !run.merged || !run.save_event || !run.regenerate_camera || !run.poll_gate) return sceneSpp;  // NoSuchMethodError pending
         cb.post_render = cb_post_render;
         cb.progress = cb_progress;
         cb.save_event = cb_save_event;
         cb.regenerate_camera = cb_regenerate_camera;
+        cb.poll_gate = cb_poll_gate;
     } else {
         run.failed = true;  // no listener: nothing to call back; merges still land in the Java array at the end
     }

@@ -2034,6 +2034,24 @@ __global__ void __launch_bounds__(256) fold_kernel(const float* __restrict__ sta
     res[3 * (size_t)gid + c] = mean;
 }
 
+// Read-back exchange of a multi-GPU group (capi.hip group_gather): the pixels of the slots of shard T, 3 floats per slot
+// in slot order, out of the image (PACK) or back into one.  Slot -> pixel is pool_slot_gid, as in the kernels that rendered
+// them; padding slots carry nothing.
+template <bool PACK>
+__global__ void __launch_bounds__(256) gather_kernel(ShardView T, int width, int height, float* __restrict__ fb, float* __restrict__ packed) {
+    const int slot = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (slot >= T.n_local) return;
+    const int gid = pool_slot_gid(T, width, height, slot);
+    if (gid >= width * height) return;
+    float* a = fb + 3 * (size_t)gid;
+    float* b = packed + 3 * (size_t)slot;
+    if (PACK) {
+        b[0] = a[0]; b[1] = a[1]; b[2] = a[2];
+    } else {
+        a[0] = b[0]; a[1] = b[1]; a[2] = b[2];
+    }
+}
+
 template <int TREE>
 __global__ void __launch_bounds__(256) trace_records_kernel(SceneView S, CameraView C, RenderOpts O, int seed,
                                                              const int* __restrict__ gids, int n,
@@ -2561,6 +2579,16 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         hipLaunchKernelGGL(render_lanes<-1>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
     else
         hipLaunchKernelGGL(render_lanes<0>, dim3(grid), dim3(block), stack_lds_bytes(S, block), stream, S, C, O, T, P, res);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(bool pack, const ShardView& T, int width, int height, float* fb, float* packed, hipStream_t stream) {
+    if (T.n_local <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((T.n_local + 255) / 256);
+    if (pack)
+        hipLaunchKernelGGL(gather_kernel<true>, dim3(grid), dim3(256), 0, stream, T, width, height, fb, packed);
+    else
+        hipLaunchKernelGGL(gather_kernel<false>, dim3(grid), dim3(256), 0, stream, T, width, height, fb, packed);
     return hipGetLastError();
 }
 

@@ -48,16 +48,23 @@ struct KernelChoice {
     int pool;    // render_pool: paths parked per wave beside the 64 in its lanes; -1 = another kernel
     int ext;     // the extended integrator (CHUNKY_OPT_SUN_SAMPLING / _EMITTERS / _BSDF / _EMITTER_NEE at non-default values)
 };
-// staging floats render_pool needs for a launch of n passes over n_local pixel slots
-// (16 x 16-pixel tiles with one rank, 256-slot runs with several: either way fewer than n_local + 32 * (width + height) + 512 slots)
-inline size_t staging_floats(int n_local, int width, int height, int n_passes) {
-    const size_t tiled = (size_t)((width + 15) / 16) * (size_t)((height + 15) / 16) * 256, runs = ((size_t)n_local + 255) / 256 * 256;
-    return 3 * (tiled > runs ? tiled : runs) * (size_t)n_passes;
+// render_pool's tiles of 256 pixel slots: the image's 16 x 16-pixel blocks with one rank (edge blocks padded), the rank's own
+// blocks or 256-slot runs with several (kernels.hip pool_slot_gid)
+inline long long pool_tile_count(const ShardView& T, int width, int height) {
+    if (T.world != 1) return ((long long)T.n_local + 255) / 256;
+    return (long long)((width + 15) / 16) * ((height + 15) / 16);
+}
+// staging floats render_pool needs for a launch of n passes over this rank's tiles
+inline size_t staging_floats(const ShardView& T, int width, int height, int n_passes) {
+    return 3 * (size_t)pool_tile_count(T, width, height) * 256 * (size_t)n_passes;
 }
 
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream,
                          KernelChoice* chosen = nullptr, float* staging = nullptr);
+// read-back exchange of a multi-GPU group: pack = true copies the pixels of this shard's slots from the image `fb` to `packed`
+// (3 floats per slot, padding slots skipped), pack = false scatters them back into an image
+hipError_t launch_gather(bool pack, const ShardView& T, int width, int height, float* fb, float* packed, hipStream_t stream);
 hipError_t launch_trace_records(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
                                 const int* gids_dev, int n, HitRecord* out, int* counts, float* radiance,
                                 hipStream_t stream);

@@ -79,7 +79,8 @@ REGEN_FN = C.CFUNCTYPE(None, C.c_void_p)
 class RunCallbacks(C.Structure):
     """chunky_run_callbacks (include/chunky_hip.h)."""
     _fields_ = [("post_render", POST_RENDER_FN), ("progress", PROGRESS_FN), ("merged", PROGRESS_FN),
-                ("save_event", SAVE_EVENT_FN), ("regenerate_camera", REGEN_FN), ("user", C.c_void_p)]
+                ("save_event", SAVE_EVENT_FN), ("regenerate_camera", REGEN_FN), ("user", C.c_void_p),
+                ("poll_gate", POST_RENDER_FN)]
 
 
 def lib() -> C.CDLL:
@@ -96,6 +97,9 @@ def lib() -> C.CDLL:
             "chunky_device_name": [C.c_int, C.c_char_p, C.c_int],
             "chunky_init": [C.c_int, C.POINTER(vp)],
             "chunky_shutdown": [vp],
+            "chunky_group_create": [vp, C.c_int, C.POINTER(vp)],
+            "chunky_group_size": [vp],
+            "chunky_group_device": [vp, C.c_int],
             "chunky_scene_create": [vp, C.POINTER(vp)],
             "chunky_scene_destroy": [vp],
             "chunky_scene_set_octree": [vp, vp, i64, C.c_int],
@@ -118,6 +122,7 @@ def lib() -> C.CDLL:
             "chunky_render_passes": [vp, vp, C.c_int, C.c_int],
             "chunky_render_sync": [vp],
             "chunky_render_read": [vp, vp, i64],
+            "chunky_render_gather": [vp],
             "chunky_render_kernel_time": [vp, C.POINTER(f32), C.POINTER(C.c_int)],
             "chunky_render_preview": [vp, vp],
             "chunky_render_phase_stats": [vp, vp, C.c_int],

@@ -44,6 +44,22 @@ class RendererInstance:
             cls._instances[device] = RendererInstance(device)
         return cls._instances[device]
 
+    @classmethod
+    def group(cls, devices) -> "RendererInstance":
+        """Several GPUs behind one context in this process (chunky_group_create): scenes are replicated, render targets
+        are cut into 16 x 16-pixel blocks dealt round-robin to the members, `read()` gathers them on member 0.
+        `devices` may repeat an index (members then share that GPU)."""
+        self = cls.__new__(cls)
+        self.device = int(devices[0])
+        self.devices = [int(d) for d in devices]
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        check(native.lib().chunky_group_create(arr, len(self.devices), C.byref(self._h)))
+        return self
+
+    def group_size(self) -> int:
+        return native.lib().chunky_group_size(self._h)
+
     @staticmethod
     def device_count() -> int:
         return native.lib().chunky_device_count()
@@ -70,7 +86,8 @@ class RendererInstance:
         if self._h:
             check(native.lib().chunky_shutdown(self._h))
             self._h = C.c_void_p()
-            RendererInstance._instances.pop(self.device, None)
+            if RendererInstance._instances.get(self.device) is self:
+                RendererInstance._instances.pop(self.device, None)
 
 
 class HipSceneLoader:
@@ -186,6 +203,10 @@ class HipPathTracingRenderer:
     def sync(self) -> None:
         check(native.lib().chunky_render_sync(self._h))
 
+    def gather(self) -> None:
+        """The read-back exchange without the copy to the host (a group: member 0's device buffer then holds the image)."""
+        check(native.lib().chunky_render_gather(self._h))
+
     def read(self) -> np.ndarray:
         out = np.empty(self.width * self.height * 3, np.float32)
         check(native.lib().chunky_render_read(self._h, ptr(out), out.size))
@@ -201,7 +222,7 @@ class HipPathTracingRenderer:
         out = np.zeros(8, np.int32)
         check(native.lib().chunky_render_kernel_info(self._h, ptr(out)))
         return {"tree": int(out[0]), "group": int(out[1]), "bvh": bool(out[2]), "blocks": int(out[3]), "pool": int(out[4]),
-                "ext": bool(out[5])}
+                "ext": bool(out[5]), "passes_per_launch": int(out[6])}
 
     def phase_stats(self, reset: bool = True) -> dict:
         out = np.zeros(24, np.uint64)
@@ -241,18 +262,21 @@ class HipPathTracingRenderer:
         return spp.value
 
     def render_ex(self, sample_buffer: np.ndarray, scene_spp: int, target_spp: int, merge_interval: int = 1024,
-                  progress=None, merged=None, save_event=None, regenerate_camera=None) -> int:
+                  progress=None, merged=None, save_event=None, regenerate_camera=None, poll_gate=None) -> int:
         """chunky_render_run_ex: the same loop with the reference's other hooks — `progress(spp)` after every launch
         (scene.spp, :144), `merged(spp)` after every merge (:172-177), `save_event(spp) -> bool` (isSaveEvent, :150) and
-        `regenerate_camera()` between launches (:146-148).  Returns the new scene.spp."""
+        `regenerate_camera()` between launches (:146-148).  `save_event` may return 2 for "merge now, no extra poll"
+        (scene.shouldFinalizeBuffer()); `poll_gate() -> bool` gates the timed poll only (`!manager.shouldFinalize()`, :154).
+        Returns the new scene.spp."""
         assert sample_buffer.dtype == np.float64 and sample_buffer.size == self.width * self.height * 3
         spp = C.c_int32(scene_spp)
         cb = native.RunCallbacks(
             native.POST_RENDER_FN((lambda _u: 1 if self.post_render() else 0) if self.post_render else 0),
             native.PROGRESS_FN((lambda _u, s: progress(s)) if progress else 0),
             native.PROGRESS_FN((lambda _u, s: merged(s)) if merged else 0),
-            native.SAVE_EVENT_FN((lambda _u, s: 1 if save_event(s) else 0) if save_event else 0),
-            native.REGEN_FN((lambda _u: regenerate_camera()) if regenerate_camera else 0), None)
+            native.SAVE_EVENT_FN((lambda _u, s: int(save_event(s))) if save_event else 0),
+            native.REGEN_FN((lambda _u: regenerate_camera()) if regenerate_camera else 0), None,
+            native.POST_RENDER_FN((lambda _u: 1 if poll_gate() else 0) if poll_gate else 0))
         rc = native.lib().chunky_render_run_ex(self._h, ptr(sample_buffer), C.byref(spp), target_spp, merge_interval, C.byref(cb))
         if rc not in (0, native.E_ABORTED):
             check(rc)

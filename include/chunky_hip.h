@@ -44,6 +44,21 @@ int chunky_device_count(void);
 int chunky_device_name(int device, char* buf, int buf_len);
 int chunky_init(int device, chunky_ctx** out);
 int chunky_shutdown(chunky_ctx* ctx);
+/* Several GPUs behind ONE context, in one process (SURVEY.md section 8b "init(device_ids[], n)", 8e; the reference holds one
+ * cl_context per JVM, RendererInstance.java:74-101, and a Chunky JVM is one process).  The handle is an ordinary chunky_ctx:
+ * every scene / render / filter entry point accepts it.  A scene created on it is replicated on every member (each chunky_scene_set_*
+ * uploads to all of them); a render target created on it is cut into blocks of 16 x 16 pixels dealt round-robin to the members
+ * (member i renders blocks b with b % n == i, `gid` stays the global pixel index, so seeds and results are those of one GPU);
+ * chunky_render_passes enqueues every member's share and returns; chunky_render_read is the one exchange per read-back: each
+ * member packs the blocks it owns, copies them to member 0 (hipMemcpyPeerAsync: xGMI where peer access exists; 1/n of the
+ * image per member, no collective library) where they are scattered into the image, which is then read back — bit for bit the
+ * one-GPU image.  `devices` may name a device more than once (members then share it: how the path is tested on a 1-GPU box).
+ * chunky_shutdown destroys the members. */
+int chunky_group_create(const int* devices, int n, chunky_ctx** out);
+/* Members of a context: 1 for chunky_init's, n for chunky_group_create's. */
+int chunky_group_size(chunky_ctx* ctx);
+/* Device index of member i. */
+int chunky_group_device(chunky_ctx* ctx, int i);
 const char* chunky_last_error(void);
 /* Library identity: "chunky-hip <version> gfx950". */
 const char* chunky_version(void);
@@ -123,6 +138,7 @@ int chunky_render_set_option(chunky_render* r, int option, int32_t value);
  * A rank renders only its tiles; every other pixel of its buffer stays 0, so a SUM reduce over
  * ranks (one RCCL collective per read-back) reproduces the 1-GPU image bit for bit. */
 int chunky_render_set_shard(chunky_render* r, int rank, int world, int tile);
+/* (On a group's render target the members split the caller's share again: member i of n renders as rank * n + i of world * n.) */
 /* Use a caller-owned device buffer (3*width*height floats) as the framebuffer, e.g. a torch tensor
  * that torch.distributed reduces over RCCL.  NULL returns to the internal buffer.
  * Ordering contract: the library runs on its own non-blocking stream and only synchronises THAT stream here.  The caller
@@ -141,15 +157,22 @@ int chunky_render_sync(chunky_render* r);
 /* Blocking read-back of the running-mean buffer, 3*width*height floats (clEnqueueReadBuffer,
  * OpenClPathTracingRenderer.java:164-166). */
 int chunky_render_read(chunky_render* r, float* out, int64_t n_floats);
+/* The exchange of chunky_render_read without the copy to the host: waits for the queued passes; on a group it then gathers
+ * every member's blocks into member 0's device buffer (chunky_render_device_buffer), which holds the whole image afterwards.
+ * On a single-device target it is chunky_render_sync. */
+int chunky_render_gather(chunky_render* r);
 /* Device time of the render kernels enqueued since the last call, from HIP events on the stream the
  * kernels run on: total milliseconds and number of launches. */
 int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches);
+/* (On a group: the largest member total — the members run concurrently — and member 0's launch count.) */
 
 /* Which kernel instantiation the most recent chunky_render_passes launch ran (no reference counterpart; the parity
  * tests assert it, so that a comparison with the oracle is a comparison of the kernel that is timed): out8 =
  * {tree form: 0 reference octree layout (K/octree.h:81-89), -1 generic wide tree, 16 + n dense top node over n levels
  * of 8x8x8 nodes; lanes per pixel (0 = one lane per pixel for the whole launch); entity-BVH phases present (K/bvh.h:22-113);
- * workgroups launched; paths parked per wave (pool kernel; -1 = the grouped kernel); extended integrator; 2 reserved}. */
+ * workgroups launched; paths parked per wave (pool kernel; -1 = the grouped kernel); extended integrator; the most passes one
+ * launch of this target carries (256, fewer when the staged samples of a launch would not fit: chunky_render_passes cuts longer
+ * requests into launches of that many); 1 reserved}.  On a group: member 0's launch. */
 int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]);
 
 /* Profile of the wave-scheduled kernel, filled only while CHUNKY_OPT_KERNEL has bit 2 set: for each of
@@ -197,10 +220,13 @@ int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_sp
  *   merged            after every merge into sample_buffer, with the spp the sample buffer now holds: the place of
  *                     scene.postProcessFrame + manager.redrawScreen (:172-177).  sample_buffer is complete and not
  *                     touched by the library while the callback runs.
- *   save_event        isSaveEvent(manager.getSnapshotControl(), scene, spp) (:150,193-195): non-zero means a snapshot or
- *                     render dump is due when the scene reaches `spp`.  The loop asks for every spp the next launch
- *                     would cover and cuts the launch there, merges at once (forced merge, :151,162-178) and polls
- *                     post_render once more after `merged` (:179-182).
+ *   save_event        the two conditions that force a merge (:150): returns 1 when isSaveEvent(manager.getSnapshotControl(),
+ *                     scene, spp) holds (:193-195) — a snapshot or render dump is due when the scene reaches `spp` — and 2 when
+ *                     only scene.shouldFinalizeBuffer() does.  The loop asks for every spp the next launch would cover and cuts
+ *                     the launch there, merges at once (:151,162-178); after a 1 it polls post_render once more after `merged`
+ *                     (the reference makes that poll for real save events only, :179-182), after a 2 it does not.
+ *   poll_gate         consulted before the TIMED poll only (the reference's `!manager.shouldFinalize()`, :154): zero skips that
+ *                     poll.  The polls before a merge (:163) and after a save event (:181) are unconditional, as in the reference.
  *   regenerate_camera between launches, for projections other than pinhole: the reference re-generates the jittered
  *                     camera-ray table on a worker while passes run (:146-148, ClCamera.java:72-104).  The hook may
  *                     call chunky_render_set_camera (from this or any other thread: the context mutex is the
@@ -213,6 +239,7 @@ typedef struct chunky_run_callbacks {
     int (*save_event)(void* user, int32_t spp);
     void (*regenerate_camera)(void* user);
     void* user;
+    int (*poll_gate)(void* user);
 } chunky_run_callbacks;
 int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
                          int32_t merge_interval, const chunky_run_callbacks* callbacks);

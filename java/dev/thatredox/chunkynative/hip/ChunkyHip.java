@@ -1,5 +1,6 @@
 package dev.thatredox.chunkynative.hip;
 
+import se.llbit.chunky.PersistentSettings;
 import se.llbit.chunky.Plugin;
 import se.llbit.chunky.main.Chunky;
 import se.llbit.chunky.main.ChunkyOptions;
@@ -19,7 +20,12 @@ public class ChunkyHip implements Plugin {
     public void attach(Chunky chunky) {
         long ctx;
         try {
-            ctx = HipNative.init(0);                       // RendererInstance.get(), ChunkyCl.java:35-40
+            // RendererInstance.get(), ChunkyCl.java:35-40.  "hipDevices" = "0" (default) or a list like "0,1,2,3,4,5,6,7":
+            // several GPUs behind one context (chunky_group_create) — nothing else in the plugin changes
+            String[] ids = PersistentSettings.settings.getString("hipDevices", "0").split(",");
+            int[] devices = new int[ids.length];
+            for (int i = 0; i < ids.length; i++) devices[i] = Integer.parseInt(ids[i].trim());
+            ctx = devices.length == 1 ? HipNative.init(devices[0]) : HipNative.groupCreate(devices);
         } catch (UnsatisfiedLinkError | RuntimeException e) {
             Log.error("Failed to load ChunkyHip. Could not load libchunky_hip or no gfx950 device.", e);
             return;

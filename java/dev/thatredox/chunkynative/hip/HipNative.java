@@ -20,6 +20,10 @@ public final class HipNative {
     public static native int deviceCount();
     public static native String deviceName(int device);
     public static native long init(int device);
+    /** chunky_group_create: several GPUs behind one context (scenes replicated, the image's 16 x 16 blocks dealt
+     *  round-robin, one gather per read-back); every other method takes the handle like init's. */
+    public static native long groupCreate(int[] devices);
+    public static native int groupSize(long ctx);
     public static native void shutdown(long ctx);
 
     // scene — replaces ClIntBuffer / ClTextureLoader / ClSky uploads (ClSceneLoader.java:52-150)
@@ -45,14 +49,20 @@ public final class HipNative {
     /** The hooks of chunky_run_callbacks (include/chunky_hip.h) — what the loop of OpenClPathTracingRenderer.java:95-184
      *  does on the Java side between launches. */
     public interface RunListener {
-        /** BooleanSupplier postRender (:153-157,163,181): true stops the loop. */
+        /** BooleanSupplier postRender (:153-157,163,181): true stops the loop.  Called for all three polls of the
+         *  reference's loop; only the timed one is gated (pollGate). */
         boolean postRender();
+        /** Gate of the TIMED poll only: the reference's {@code !manager.shouldFinalize()} (:154).  The polls before a
+         *  merge (:163) and after a save event (:181) are unconditional. */
+        boolean pollGate();
         /** After every launch: the new scene.spp (:144). */
         void progress(int sceneSpp);
         /** After every merge; the sample buffer is complete (:172-177: postProcessFrame + redrawScreen). */
         void merged(int sampleSpp);
-        /** isSaveEvent(snapshotControl, scene, spp) (:150,193-195): a snapshot / dump is due at this spp. */
-        boolean saveEvent(int spp);
+        /** The forced-merge condition of :150 — 1: isSaveEvent(snapshotControl, scene, spp) (:193-195), a snapshot /
+         *  dump is due at this spp (merge at once, then one more postRender poll, :179-182); 2: only
+         *  scene.shouldFinalizeBuffer() (merge at once, no extra poll); 0: neither. */
+        int saveEvent(int spp);
         /** Between launches: re-generate jittered camera rays for non-pinhole projections (:146-148). */
         void regenerateCamera();
     }

@@ -1,5 +1,6 @@
 package dev.thatredox.chunkynative.hip;
 
+import dev.thatredox.chunkynative.opencl.renderer.scene.ClCamera;   // the reference's class, patched as INTEGRATION.md section 2 says
 import se.llbit.chunky.main.Chunky;
 import se.llbit.chunky.renderer.DefaultRenderManager;
 import se.llbit.chunky.renderer.Renderer;
@@ -43,25 +44,26 @@ public class HipPathTracingRenderer implements Renderer {
         long render = HipNative.renderCreate(ctx, sceneLoader.handle(), scene.width, scene.height);
         final ForkJoinTask<?>[] cameraGenTask = {Chunky.getCommonThreads().submit(() -> 0)};   // :97
         try {
-            HipCamera.apply(render, scene, true);                            // camera.generate(renderLock, true), :88
-            final boolean needGenerate = HipCamera.needGenerate(scene);
+            final ClCamera camera = new ClCamera(scene);                     // :79; patched: ends in HipNative.renderSetCamera
+            camera.apply(render);
+            camera.generate(render, true);                                   // camera.generate(renderLock, true), :88
             final SnapshotControl snapshots = manager.getSnapshotControl();
             int spp = HipNative.renderRun(render, scene.width, scene.height, scene.getSampleBuffer(), scene.spp,
                     scene.getTargetSpp(), 1024, new HipNative.RunListener() {
-                        @Override public boolean postRender() {             // :153-157 — the reference skips the poll while
-                            return !manager.shouldFinalize() && postRender.getAsBoolean();   // the manager finalizes
-                        }
+                        @Override public boolean postRender() { return postRender.getAsBoolean(); }   // :155,163,181
+                        @Override public boolean pollGate() { return !manager.shouldFinalize(); }     // :154, the timed poll only
                         @Override public void progress(int sceneSpp) { scene.spp = sceneSpp; }     // :144
                         @Override public void merged(int sampleSpp) {        // :172-177
                             scene.postProcessFrame(TaskTracker.Task.NONE);
                             manager.redrawScreen();
                         }
-                        @Override public boolean saveEvent(int spp) {        // :150,193-195
-                            return scene.shouldFinalizeBuffer() || snapshots.saveSnapshot(scene, spp) || snapshots.saveRenderDump(scene, spp);
+                        @Override public int saveEvent(int spp) {            // :150: 1 = isSaveEvent (:193-195), 2 = finalize only
+                            if (snapshots.saveSnapshot(scene, spp) || snapshots.saveRenderDump(scene, spp)) return 1;
+                            return scene.shouldFinalizeBuffer() ? 2 : 0;
                         }
                         @Override public void regenerateCamera() {           // :146-148 — fresh jitter while passes run; the
-                            if (needGenerate && cameraGenTask[0].isDone())   // library's context mutex plays renderLock
-                                cameraGenTask[0] = Chunky.getCommonThreads().submit(() -> HipCamera.apply(render, scene, true));
+                            if (camera.needGenerate && cameraGenTask[0].isDone())   // library's context mutex plays renderLock
+                                cameraGenTask[0] = Chunky.getCommonThreads().submit(() -> camera.generate(render, true));
                         }
                     });
             scene.spp = spp;

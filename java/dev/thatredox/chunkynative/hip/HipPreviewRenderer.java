@@ -1,5 +1,6 @@
 package dev.thatredox.chunkynative.hip;
 
+import dev.thatredox.chunkynative.opencl.renderer.scene.ClCamera;   // the reference's class, patched as INTEGRATION.md section 2 says
 import se.llbit.chunky.renderer.DefaultRenderManager;
 import se.llbit.chunky.renderer.Renderer;
 import se.llbit.chunky.renderer.ResetReason;
@@ -36,7 +37,9 @@ public class HipPreviewRenderer implements Renderer {
         sceneLoader.ensureLoad(scene);                                                   // :54
         long render = HipNative.renderCreate(ctx, sceneLoader.handle(), scene.width, scene.height);
         try {
-            HipCamera.apply(render, scene, false);                                       // camera.generate(null, false), :72
+            ClCamera camera = new ClCamera(scene);                                       // :62
+            camera.apply(render);
+            camera.generate(render, false);                                              // camera.generate(null, false), :72
             HipNative.renderPreview(render, scene.width, scene.height, imageData);                                 // kernel launch + blocking read, :104-110
             manager.redrawScreen();                                                      // :112
             postRender.getAsBoolean();                                                   // :113

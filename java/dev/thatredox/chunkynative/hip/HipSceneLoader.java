@@ -11,6 +11,8 @@ import dev.thatredox.chunkynative.common.export.primitives.PackedMaterial;
 import dev.thatredox.chunkynative.common.export.primitives.PackedSun;
 import dev.thatredox.chunkynative.common.export.texture.AbstractTextureLoader;
 import dev.thatredox.chunkynative.common.state.SkyState;
+import dev.thatredox.chunkynative.opencl.renderer.export.ClTextureLoader;   // the reference's classes, patched as
+import dev.thatredox.chunkynative.opencl.renderer.scene.ClSky;              // INTEGRATION.md section 2 says
 import se.llbit.chunky.renderer.ResetReason;
 import se.llbit.chunky.renderer.scene.Scene;
 
@@ -45,7 +47,7 @@ public class HipSceneLoader extends AbstractSceneLoader {
         if (this.modCount != modCount) {                                     // ClSceneLoader.java:40-48: the sky is baked again
             SkyState newSky = new SkyState(sceneObj.sky(), sceneObj.sun());  // only when its state (or the sun's) changed
             if (!newSky.equals(skyState)) {
-                HipSky.upload(scene, sceneObj);
+                new ClSky(scene, sceneObj);   // patched: bakes as before (ClSky.java:41-58), ends in HipNative.sceneSetSky
                 skyState = newSky;
                 skyLoaded = true;
             }
@@ -74,7 +76,7 @@ public class HipSceneLoader extends AbstractSceneLoader {
         return true;
     }
 
-    @Override protected AbstractTextureLoader createTextureLoader() { return new HipTextureLoader(scene); }
+    @Override protected AbstractTextureLoader createTextureLoader() { return new ClTextureLoader(scene); }
     @Override protected ResourcePalette<PackedBlock> createBlockPalette() { return new HipPalette<>(scene, HipNative.PALETTE_BLOCK); }
     @Override protected ResourcePalette<PackedMaterial> createMaterialPalette() { return new HipPalette<>(scene, HipNative.PALETTE_MATERIAL); }
     @Override protected ResourcePalette<PackedAabbModel> createAabbModelPalette() { return new HipPalette<>(scene, HipNative.PALETTE_AABB); }

@@ -41,6 +41,7 @@ struct JNIEnv {
     jclass GetObjectClass(jobject obj);
     jmethodID GetMethodID(jclass cls, const char* name, const char* sig);
     jboolean CallBooleanMethod(jobject obj, jmethodID m, ...);
+    jint CallIntMethod(jobject obj, jmethodID m, ...);
     void CallVoidMethod(jobject obj, jmethodID m, ...);
     jstring NewStringUTF(const char* utf);
     jsize GetArrayLength(jarray a);

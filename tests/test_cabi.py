@@ -43,3 +43,18 @@ def test_no_device_means_error_not_fallback():
     from chunkyclplugin_amd.renderer import RendererInstance
     with pytest.raises(native.ChunkyHipError):
         RendererInstance(0)
+
+
+def test_group_without_devices_fails_loudly():
+    """chunky_group_create has no fallback either; bad arguments are errors, not crashes."""
+    L = native.lib()
+    h = C.c_void_p()
+    two = (C.c_int * 2)(0, 0)
+    assert L.chunky_group_create(None, 2, C.byref(h)) == native.E_INVALID
+    assert L.chunky_group_create(two, 0, C.byref(h)) == native.E_INVALID
+    assert L.chunky_group_create(two, 2, None) == native.E_INVALID
+    assert L.chunky_group_size(None) == native.E_INVALID
+    assert L.chunky_render_gather(None) == native.E_INVALID
+    if L.chunky_device_count() == 0:
+        assert L.chunky_group_create(two, 2, C.byref(h)) == native.E_NO_DEVICE and not h.value
+        assert b"member 0" in L.chunky_last_error()

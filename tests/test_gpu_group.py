@@ -1,0 +1,145 @@
+"""Several GPUs behind ONE context in one process (chunky_group_create; SURVEY.md section 8b "init(device_ids[], n)" /
+8e): scenes replicated on every member, the image's 16 x 16-pixel blocks dealt round-robin, one gather of the owned
+blocks per read-back.  A 1-GPU box runs it with members that share device 0 — every piece of the path (fan-out of the
+uploads, per-member shards, concurrent launches on the members' streams, pack / copy / scatter, the host loop on top) is
+the code n distinct GPUs run; only the copy is device-to-device instead of peer-to-peer.  The image must be bit for bit
+the one-context image, the reference's golden image and the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_scenes as gs
+from chunkyclplugin_amd import native, scenes
+from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def renderer_on(instance, sc):
+    loader = HipSceneLoader(instance)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, sc.width, sc.height)
+    r.set_camera(sc.projector_type, sc.camera)
+    return loader, r
+
+
+@pytest.fixture(scope="module")
+def group3():
+    g = RendererInstance.group([0, 0, 0])
+    yield g
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["outdoor", "entities", "pregen", "indoor"])
+def test_group_image_is_the_reference_golden(group3, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sc = gs.make(name)
+    assert group3.group_size() == 3
+    loader, r = renderer_on(group3, sc)
+    r.render_passes(g["seeds"])
+    np.testing.assert_array_equal(bits(r.read()), bits(g["res"]))
+    np.testing.assert_array_equal(r.preview(), g["preview"])
+    info = r.kernel_info()
+    assert info["pool"] >= 0  # the members run the pool kernel on their block shares
+    r.close()
+    loader.close()
+
+
+def test_group_continues_the_running_mean_and_resets(group3, gpu_instance, port):
+    """Two launches (bufferSpp continues), a read in between, a reset, and again: the same as one context."""
+    sc = scenes.outdoor_world(chunks=4, height=64, seed=11, width=200, img_height=120, aabb_frac=0.05, quad_frac=0.03)
+    seeds = native.java_random_ints(9)
+    lg, rg = renderer_on(group3, sc)
+    l1, r1 = renderer_on(gpu_instance, sc)
+    for r in (rg, r1):
+        r.render_passes(seeds[:4])
+    a, b = rg.read(), r1.read()
+    np.testing.assert_array_equal(bits(a), bits(b))
+    for r in (rg, r1):
+        r.render_passes(seeds[4:], first_buffer_spp=4)
+    a, b = rg.read(), r1.read()
+    np.testing.assert_array_equal(bits(a), bits(b))
+    np.testing.assert_array_equal(bits(a), bits(port.render_passes(sc, seeds)))
+    rg.reset()
+    rg.render_passes(seeds[:2])
+    np.testing.assert_array_equal(bits(rg.read()), bits(port.render_passes(sc, seeds[:2])))
+    for x in (rg, r1, lg, l1):
+        x.close()
+
+
+def test_group_host_loop(group3, port):
+    """chunky_render_run_ex on a group: the reference's pass loop (seeds, read-back cadence, double merge) over the members."""
+    sc = gs.make("outdoor")
+    lg, rg = renderer_on(group3, sc)
+    buf = np.zeros(3 * sc.width * sc.height, np.float64)
+    merges = []
+    spp = rg.render_ex(buf, 0, 10, merge_interval=4, merged=merges.append)
+    assert spp == 10 and merges == [4, 8, 10]
+    want = np.zeros_like(buf)
+    seeds = native.java_random_ints(10)
+    done = 0
+    for m in (4, 4, 2):  # OpenClPathTracingRenderer.java:167-173
+        part = port.render_passes(sc, seeds[done:done + m]).astype(np.float64)
+        want = (want * done + part * m) * (1.0 / (done + m))
+        done += m
+    np.testing.assert_array_equal(buf, want)
+    rg.close()
+    lg.close()
+
+
+def test_group_inside_an_outer_shard(gpu_instance, port):
+    """A group that is itself rank 1 of 2 (chunky_render_set_shard on the group): its members render as ranks 2 and 3 of 4;
+    with a plain context as rank 0 of 2 the two halves add up to the whole image."""
+    sc = scenes.outdoor_world(chunks=4, height=64, seed=12, width=160, img_height=96, aabb_frac=0.05, quad_frac=0.03)
+    seeds = native.java_random_ints(3)
+    g2 = RendererInstance.group([0, 0])
+    lg, rg = renderer_on(g2, sc)
+    rg.set_shard(1, 2, 0)
+    l0, r0 = renderer_on(gpu_instance, sc)
+    r0.set_shard(0, 2, 0)
+    for r in (rg, r0):
+        r.render_passes(seeds)
+    half1, half0 = rg.read(), r0.read()
+    assert (half1.reshape(-1, 3).any(axis=1) & half0.reshape(-1, 3).any(axis=1)).sum() == 0  # disjoint blocks
+    np.testing.assert_array_equal(bits(half0 + half1), bits(port.render_passes(sc, seeds)))
+    for x in (rg, r0, lg, l0):
+        x.close()
+    g2.close()
+
+
+def test_group_on_the_timed_workload(gpu_instance, port):
+    """BASELINE configs[2] at 1920x1080 cut over four members: the timed instantiation on every member, whole rows against
+    the oracle, and the gather leaves the image in member 0's device buffer."""
+    W, H, P = 1920, 1080, 16
+    sc = scenes.cached_outdoor_world(chunks=32, height=256, width=W, img_height=H)
+    seeds = native.java_random_ints(P)
+    g4 = RendererInstance.group([0, 0, 0, 0])
+    lg, rg = renderer_on(g4, sc)
+    rg.render_passes(seeds, sync=False)
+    rg.gather()
+    info = rg.kernel_info()
+    assert (info["tree"], info["pool"], info["bvh"], info["passes_per_launch"]) == (17, 56, False, 256)
+    got = rg.read().reshape(-1, 3)
+    rows = (3, 271, 540, 811, 1077)
+    gids = np.concatenate([np.arange(y * W, (y + 1) * W) for y in rows]).astype(np.int32)
+    ref = port.render_gids(sc, seeds, gids, threads=os.cpu_count() or 8).reshape(-1, 3)[gids]
+    np.testing.assert_array_equal(bits(got[gids]), bits(ref))
+    assert np.isfinite(got).all() and got.any(axis=1).mean() > 0.99  # every block arrived
+    rg.close()
+    lg.close()
+    g4.close()
+
+
+def test_group_errors():
+    L = native.lib()
+    import ctypes as C
+    h = C.c_void_p()
+    arr = (C.c_int * 2)(0, 99)
+    assert L.chunky_group_create(arr, 2, C.byref(h)) == native.E_NO_DEVICE and not h.value
+    assert L.chunky_group_create(arr, 0, C.byref(h)) == native.E_INVALID

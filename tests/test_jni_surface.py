@@ -76,14 +76,14 @@ def test_glue_calls_only_declared_c_functions():
     assert used <= declared, used - declared
     fields = re.search(r"typedef struct chunky_run_callbacks \{(.*?)\}", header, flags=re.S).group(1)
     members = re.findall(r"\(\*(\w+)\)", fields)
-    assert members == ["post_render", "progress", "merged", "save_event", "regenerate_camera"]
+    assert members == ["post_render", "progress", "merged", "save_event", "regenerate_camera", "poll_gate"]
     glue = open(GLUE).read()
     for m in members:
         assert f"cb_{m}" in glue, m
     # the listener method names / descriptors the glue looks up are the ones HipNative.RunListener declares
     native_src = strip_comments(open(os.path.join(JAVA, "HipNative.java")).read())
     for name, sig in re.findall(r'GetMethodID\(cls, "(\w+)", "([^"]+)"\)', glue):
-        ret = {"Z": "boolean", "V": "void"}[sig[-1]]
+        ret = {"Z": "boolean", "V": "void", "I": "int"}[sig[-1]]
         arg = "int \\w+" if "(I)" in sig else ""
         assert re.search(rf"{ret}\s+{name}\s*\(\s*{arg}\s*\)\s*;", native_src), (name, sig)
 
