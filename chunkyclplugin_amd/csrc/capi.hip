@@ -908,11 +908,12 @@ static int each_part(chunky_render* r, F call) {
 #define FAN_RENDER(r, expr) \
     if ((r) && !(r)->parts.empty()) return each_part((r), [&](chunky_render* m_) { return expr; })
 
-// member i of n renders rank * n + i of world * n of the image (rank / world: the caller's own share, chunky_render_set_shard)
+// member i of n renders rank + world * i of world * n of the image (rank / world: the caller's own share, chunky_render_set_shard:
+// its tiles are t = rank (mod world); dealing them round-robin to n members gives member i the tiles t = rank + world * i (mod world * n))
 static int group_apply_shards(chunky_render* r) {
     const int n = (int)r->parts.size();
     for (int i = 0; i < n; i++)
-        if (int rc = chunky_render_set_shard(r->parts[(size_t)i], r->outer.rank * n + i, r->outer.world * n, r->outer.tile)) return rc;
+        if (int rc = chunky_render_set_shard(r->parts[(size_t)i], r->outer.rank + r->outer.world * i, r->outer.world * n, r->outer.tile)) return rc;
     return CHUNKY_OK;
 }
 
@@ -1579,6 +1580,25 @@ extern "C" int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const flo
     HIP_TRY(launch_math_selftest(which, n, (const float*)da.p, (const float*)db.p, (float*)dout.p, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_selftest_helpers(chunky_scene* scene, int which, int tree, int n, const float* in, float* out, int32_t* tree_used) {
+    if (scene && !scene->replicas.empty()) return chunky_selftest_helpers(scene->replicas[0], which, tree, n, in, out, tree_used);
+    LOCK_SCENE(scene);
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(CHUNKY_E_INVALID, "selftest_helpers: bad arguments");
+    if (n == 0) return CHUNKY_OK;
+    SceneView S;
+    if (int rc = scene_view(scene, &S)) return rc;
+    DevBuf din, dout;
+    hipStream_t st = scene->ctx->stream;
+    HIP_TRY(din.upload(in, (size_t)n * 32 * sizeof(float), st));
+    HIP_TRY(hipMalloc(&dout.p, (size_t)n * 12 * sizeof(float)));
+    int used = 0;
+    HIP_TRY(launch_helpers_selftest(S, which, tree, n, (const float*)din.p, (float*)dout.p, &used, st));
+    HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n * 12 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (tree_used) *tree_used = used;
     return CHUNKY_OK;
 }
 

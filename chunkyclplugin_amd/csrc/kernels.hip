@@ -2141,6 +2141,141 @@ __global__ void math_selftest_kernel(int which, int n, const float* __restrict__
     out[i] = r;
 }
 
+// Helper-level known answers (chunky_selftest_helpers): the device functions the kernels are made of, one call per input
+// row, against tests/golden/helpers.npz — the answers of the reference object's own exported helpers (oracle/ref_shim.cpp
+// ref_helpers has the row layouts and the `which` numbering, K/primitives.h:30-409, K/sky.h:42-106, K/kernel.h:46-98,
+// K/block.h:30-118, K/octree.h:41-109, K/bvh.h:22-113).  18 = the world-BVH walk as render_pool performs it (rwalk_step on
+// the aligned records, to-visit stacks in LDS), same rows and answers as 15.
+constexpr int kHelperIn = 32, kHelperOut = 12;
+struct ScratchStack {
+    int a[kBvhStackEntries];
+    DEV void push(int slot, int v) { a[slot] = v; }
+    DEV int pop(int slot) { return a[slot]; }
+};
+template <int TREE>
+__global__ void __launch_bounds__(64) helpers_selftest_kernel(SceneView S, int which, int n, const float* __restrict__ in_rows,
+                                                              float* __restrict__ out_rows) {
+    extern __shared__ int lds[];
+    const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= n) return;
+    const float* in = in_rows + (size_t)r * kHelperIn;
+    float out[kHelperOut];
+    for (int k = 0; k < kHelperOut; k++) out[k] = 0;
+    Hit h;
+    h.distance = rt_inf();
+    h.material = 0;
+    h.normal = mk3(0, 0, 0);
+    h.color = f4{0, 0, 0, 0};
+    h.emittance = 0;
+    h.spec = 0;
+    const f3 a6 = mk3(in[6], in[7], in[8]), a9 = mk3(in[9], in[10], in[11]);
+    switch (which) {
+        case 0: out[0] = box_quick(in[0], in[1], in[2], in[3], in[4], in[5], a6, rcp3(a9)); break;
+        case 1: out[0] = box_exit(in[0], in[1], in[2], in[3], in[4], in[5], a6, rcp3(a9)); break;
+        case 2: case 3: {
+            const f3 inv = which == 2 ? rcp3(mk3(in[12], in[13], in[14])) : rcp3(a9);
+            const Slabs sl = which == 2 ? slabs(0, 1, 0, 1, 0, 1, a6, inv) : slabs(in[0], in[1], in[2], in[3], in[4], in[5], a6, inv);
+            const float tn = slab_near(sl), tf = slab_far(sl);
+            if (tf < tn) {
+                out[0] = rt_nan();
+            } else {
+                const Face f = which == 2 ? face_unit(sl, tn, a6 + a9 * tn) : face_map2(sl, tn, a6 + a9 * tn);
+                out[0] = tn; out[1] = f.n.x; out[2] = f.n.y; out[3] = f.n.z; out[4] = f.u; out[5] = f.v;
+            }
+            break;
+        }
+        case 4: {
+            const f3 pos = mk3(in[4], in[5], in[6]), dir = mk3(in[7], in[8], in[9]);
+            out[0] = block_hit(S, __float_as_int(in[0]), (int)in[1], (int)in[2], (int)in[3], pos, dir, rcp3(dir), h);
+            out[1] = h.normal.x; out[2] = h.normal.y; out[3] = h.normal.z;
+            out[4] = h.color.x; out[5] = h.color.y; out[6] = h.color.z; out[7] = h.color.w; out[8] = h.emittance;
+            break;
+        }
+        case 6: {
+            f3 nn = mk3(0, 0, 0);
+            float u = 0, v = 0;
+            int mat = 0;
+            out[0] = triangle_hit((const int*)in, in[26], mk3(in[20], in[21], in[22]), mk3(in[23], in[24], in[25]), nn, u, v, mat);
+            out[1] = nn.x; out[2] = nn.y; out[3] = nn.z; out[4] = u; out[5] = v; out[6] = __int_as_float(mat);
+            break;
+        }
+        case 7: {
+            unsigned rng = (unsigned)__float_as_int(in[0]);
+            const f3 d = sun_sample(S, rng);
+            out[0] = d.x; out[1] = d.y; out[2] = d.z;
+            out[3] = rt_fabs(dot(d, mk3(in[1], in[2], in[3])));  // record.emittance, K/sky.h:90 (sample_path / shade_phase write it the same way)
+            out[4] = __int_as_float((int)rng);
+            break;
+        }
+        case 8: {
+            f4 c = f4{in[3], in[4], in[5], in[6]};
+            const f4 before = c;
+            sun_disc(S, mk3(in[0], in[1], in[2]), c);
+            out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;  // (alpha: the kernels never read it; the test compares x, y, z)
+            out[4] = (c.x != before.x || c.y != before.y || c.z != before.z) ? 1.0f : 0.0f;
+            break;
+        }
+        case 9: {
+            const f4 c = sky_color(S, mk3(in[0], in[1], in[2]));
+            out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+            break;
+        }
+        case 10: {
+            unsigned rng = (unsigned)__float_as_int(in[0]);
+            const f3 d = diffuse_bounce(mk3(in[1], in[2], in[3]), rng);
+            const f3 o = mk3(in[4], in[5], in[6]) + d * kOffset;
+            out[0] = d.x; out[1] = d.y; out[2] = d.z; out[3] = o.x; out[4] = o.y; out[5] = o.z; out[6] = __int_as_float((int)rng);
+            break;
+        }
+        case 11: {
+            const f4 c = unpack_unorm8(atlas_texel(S, in[0], in[1], __float_as_int(in[2]), __float_as_int(in[3])));
+            out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+            break;
+        }
+        case 12: {
+            out[0] = material_sample(S, __float_as_int(in[0]), in[1], in[2], h) ? 1.0f : 0.0f;
+            out[1] = h.color.x; out[2] = h.color.y; out[3] = h.color.z; out[4] = h.color.w; out[5] = h.emittance;
+            break;
+        }
+        case 14: case 15: case 18: {
+            const f3 o = mk3(in[0], in[1], in[2]), d = mk3(in[3], in[4], in[5]);
+            bool hit = false;
+            if (which == 14) {
+                hit = octree_hit<TREE>(S, o, d, 256, h);
+            } else if (which == 15) {
+                ScratchStack stack;
+                h.distance = in[6];
+                hit = bvh_hit(S, S.world_bvh, o, d, h, stack);
+            } else {
+                LaneState L;
+                L.o = o; L.d = d; L.inv = rcp3(d);
+                L.h = h;
+                L.h.distance = in[6];
+                L.shadow = false; L.oct_hit = false; L.trace_hit = false;
+                L.bvh_dist = in[6];
+                L.pid = (int)threadIdx.x;
+                SceneView W = S;
+                W.actor_bvh_empty = 1;  // the world BVH alone, like row 15
+                PathStacks K{lds, (int)blockDim.x};
+                int st = rbvh_enter(W, L, 0);
+                while (st == ST_BVH) st = rwalk_step(W, L, K);
+                hit = L.trace_hit;
+                h = L.h;
+            }
+            int k = 0;
+            out[k++] = hit ? 1.0f : 0.0f;
+            out[k++] = h.distance;
+            if (which == 14) out[k++] = __int_as_float(h.material);
+            out[k++] = h.normal.x; out[k++] = h.normal.y; out[k++] = h.normal.z;
+            out[k++] = h.color.x; out[k++] = h.color.y; out[k++] = h.color.z; out[k++] = h.color.w;
+            out[k++] = h.emittance;
+            break;
+        }
+        default: break;
+    }
+    for (int k = 0; k < kHelperOut; k++) out_rows[(size_t)r * kHelperOut + k] = out[k];
+}
+
 // ---------------------------------------------------------------------------------------------
 // `filter` — tonemap/include/post_processing_filter.cl:5-51: 3 doubles per pixel in, one ARGB word
 // out; 28 bytes of HBM traffic per pixel and nothing to reuse, so the kernel is a streaming copy
@@ -2620,6 +2755,32 @@ hipError_t launch_preview(int variant, const SceneView& S, const CameraView& C, 
 
 hipError_t launch_math_selftest(int which, int n, const float* a, const float* b, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(math_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, which, n, a, b, out);
+    return hipGetLastError();
+}
+
+// `tree`: 0 the reference layout, 1 the wide tree in the form the render kernels would pick for this scene (row 14 only)
+hipError_t launch_helpers_selftest(const SceneView& S, int which, int tree, int n, const float* in, float* out, int* tree_used, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (which == 18 && !(S.bvh_rec && S.tri_rec && S.mat8)) return hipErrorNotSupported;
+    int t = 0;
+    if (tree && S.wide) {
+        t = S.wide_nlev <= 4 ? 16 + S.wide_nlev - 1 : -1;
+        for (int i = 1; i < S.wide_nlev; i++)
+            if (S.wide_bits[i] != 3) t = -1;
+    }
+    typedef void (*Kernel)(SceneView, int, int, const float*, float*);
+    Kernel k;
+    switch (t) {
+        case 0: k = helpers_selftest_kernel<0>; break;
+        case 16: k = helpers_selftest_kernel<16>; break;
+        case 17: k = helpers_selftest_kernel<17>; break;
+        case 18: k = helpers_selftest_kernel<18>; break;
+        default: t = -1; k = helpers_selftest_kernel<-1>; break;
+    }
+    if (tree_used) *tree_used = t;
+    const int entries = S.bvh_stack_entries > 0 && S.bvh_stack_entries < kBvhStackEntries ? S.bvh_stack_entries : kBvhStackEntries;
+    const size_t lds = which == 18 ? (size_t)entries * 64 * sizeof(int) : 0;
+    hipLaunchKernelGGL(k, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, stream, S, which, n, in, out);
     return hipGetLastError();
 }
 

@@ -77,6 +77,8 @@ hipError_t launch_filter(long long n_pixels, float exposure, const double* in, u
 // threshold table, for `count` consecutive float bit patterns
 hipError_t launch_gamma_scan(unsigned first, unsigned long long count, int curve, const float* thresholds, unsigned long long* mismatches,
                              float* worst, hipStream_t stream);
+// helper-level known answers (kernels.hip helpers_selftest_kernel): rows of 32 floats in, 12 out
+hipError_t launch_helpers_selftest(const SceneView& S, int which, int tree, int n, const float* in, float* out, int* tree_used, hipStream_t stream);
 hipError_t launch_math_selftest(int which, int n, const float* a, const float* b, float* out, hipStream_t stream);
 
 }  // namespace chunky

@@ -132,6 +132,7 @@ def lib() -> C.CDLL:
             "chunky_render_run_ex": [vp, vp, C.POINTER(i32), i32, i32, C.POINTER(RunCallbacks)],
             "chunky_java_random_ints": [i64, vp, C.c_int],
             "chunky_selftest_math": [vp, C.c_int, C.c_int, vp, vp, vp],
+            "chunky_selftest_helpers": [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(i32)],
             "chunky_selftest_gamma_scan": [vp, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(f32)],
             "chunky_filter_frame": [vp, C.c_int, C.c_int, C.c_double, vp, vp, C.c_int],
             "chunky_filter_gamma_thresholds": [vp],

@@ -133,6 +133,15 @@ class HipSceneLoader:
         check(native.lib().chunky_scene_emitters(self._h, ptr(out), n.value, C.byref(n)))
         return out[:n.value]
 
+    def selftest_helpers(self, which: int, rows, tree: int = 1):
+        """chunky_selftest_helpers: the device counterpart of reference helper `which` on rows of 32 floats; returns
+        (rows of 12 floats, tree form used for row kind 14)."""
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 32)
+        out = np.zeros((len(rows), 12), np.float32)
+        used = C.c_int32()
+        check(native.lib().chunky_selftest_helpers(self._h, which, tree, len(rows), ptr(rows), ptr(out), C.byref(used)))
+        return out, used.value
+
     def load_octree(self, tree_data, depth: int, block_mapping) -> None:
         """`ClSceneLoader.loadOctree` (ClSceneLoader.java:52-63): raw PackedOctree.treeData +
         blockMapping, remapped natively."""

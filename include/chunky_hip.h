@@ -138,7 +138,7 @@ int chunky_render_set_option(chunky_render* r, int option, int32_t value);
  * A rank renders only its tiles; every other pixel of its buffer stays 0, so a SUM reduce over
  * ranks (one RCCL collective per read-back) reproduces the 1-GPU image bit for bit. */
 int chunky_render_set_shard(chunky_render* r, int rank, int world, int tile);
-/* (On a group's render target the members split the caller's share again: member i of n renders as rank * n + i of world * n.) */
+/* (On a group's render target the members split the caller's share again: member i of n renders as rank + world * i of world * n.) */
 /* Use a caller-owned device buffer (3*width*height floats) as the framebuffer, e.g. a torch tensor
  * that torch.distributed reduces over RCCL.  NULL returns to the internal buffer.
  * Ordering contract: the library runs on its own non-blocking stream and only synchronises THAT stream here.  The caller
@@ -279,6 +279,19 @@ int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int depth, const
 
 /* ---- self test: evaluate the rt_math.h contract on the device (bit-compared with the host by tests) */
 int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const float* a, const float* b, float* out);
+
+/* ---- self test: helper-level known answers (no reference counterpart as an entry point).
+ * Evaluates, one call per input row, the device functions the kernels are made of — the counterparts of the reference's
+ * helpers K/primitives.h:30-162 (AABB_quick_intersect 0, AABB_exit 1, AABB_full_intersect 2, AABB_full_intersect_map_2 3),
+ * K/block.h:30-118 (BlockPalette_intersectBlock 4: cube, AABB-model and quad-model blocks with their materials),
+ * K/primitives.h:335-409 (Triangle_new + Triangle_intersect 6), K/sky.h:42-106 (Sun_sampleDirection 7, Sun_intersect 8,
+ * Sky_intersect 9), K/kernel.h:46-98 (nextPath 10), K/textureAtlas.h:18-28 (Atlas_read_uv 11), K/material.h:31-82
+ * (Material_get + Material_sample 12), K/octree.h:41-109 (Octree_octreeIntersect 14; `tree` 0 = the reference layout, 1 = the
+ * wide tree in the form the render kernels pick, reported in *tree_used), K/bvh.h:22-113 (Bvh_intersect on the world BVH: 15
+ * on the packed arrays, 18 as the pool kernel walks its aligned records) — on the scene's own palettes, atlas, sky and sun.
+ * Rows are 32 floats in and 12 out (ints as their bit patterns); the layouts are listed in oracle/ref_shim.cpp ref_helpers,
+ * which produced tests/golden/helpers.npz from the reference object itself.  A parity failure then names a function, not a pixel. */
+int chunky_selftest_helpers(chunky_scene* scene, int which, int tree, int n, const float* in_rows, float* out_rows, int32_t* tree_used);
 
 /* ---- self test of the tone map's byte estimate (no reference counterpart): `count` consecutive float bit patterns from
  * first_bits through the fast path of the GAMMA (curve 0) or ACES (curve 2) filter (hardware log2 / exp2 / reciprocal

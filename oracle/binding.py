@@ -147,6 +147,19 @@ class _Lib:
         getattr(self.lib, self.prefix + "_pow")(a.size, _ptr(a), _ptr(b), _ptr(out))
         return out
 
+    def helpers(self, sc, which: int, rows) -> np.ndarray:
+        """Helper-level known answers: helper `which` (numbering and row layouts in oracle/ref_shim.cpp ref_helpers) on rows
+        of 32 floats; 12 floats out per row.  The reference build calls the reference's own exported functions, the
+        restatement its counterparts."""
+        h = sc if isinstance(sc, SceneHandle) else SceneHandle(sc)
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 32)
+        out = np.zeros((len(rows), 12), np.float32)
+        f = getattr(self.lib, self.prefix + "_helpers")
+        f.argtypes = [C.POINTER(OracleScene), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        f.restype = None
+        f(C.byref(h.struct), int(which), len(rows), _ptr(rows), _ptr(out))
+        return out
+
     def math(self, which: int, a, b=None) -> np.ndarray:
         a = np.ascontiguousarray(a, np.float32)
         b = np.ascontiguousarray(a if b is None else b, np.float32)
@@ -305,6 +318,11 @@ _port: Optional[PortLib] = None
 
 
 def _make(target: str) -> None:
+    # CHUNKY_ORACLE_NO_BUILD=1 (set by tools/pmc.sh / kt_trace.sh after they have built everything): never spawn a child —
+    # under `rocprofv3 --pmc` the profiler's preloaded library initialises the GPU in every child process, and a child
+    # that then execs a compiler is exactly the exec-after-GPU-init this pool forbids
+    if os.environ.get("CHUNKY_ORACLE_NO_BUILD"):
+        return
     subprocess.run(["make", "-C", HERE, target], check=True, stdout=subprocess.DEVNULL,
                    stderr=subprocess.PIPE)
 

@@ -647,6 +647,115 @@ static void put_hit(OracleHit* h, int hit, const Record* r) {
     h->point[0] = r->point.x; h->point[1] = r->point.y; h->point[2] = r->point.z;
 }
 
+/* ---- helper-level known answers: the restatement's counterparts of the reference helpers oracle/ref_shim.cpp ref_helpers
+ * drives, on the same rows (row layout and `which` numbering: see there; tests/golden/helpers.npz holds the reference's
+ * answers). */
+#define HELPER_IN 32
+#define HELPER_OUT 12
+static inline int f2i(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float i2f(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline v3 ld3(const float* p) { return V3(p[0], p[1], p[2]); }
+static inline v3 rcp3v(v3 d) { return V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+void port_helpers(const OracleScene* s, int which, int n, const float* in_rows, float* out_rows) {
+    const Sun sun = sun_new(s->sun);
+    for (int r = 0; r < n; r++) {
+        const float* in = in_rows + (size_t)r * HELPER_IN;
+        float* out = out_rows + (size_t)r * HELPER_OUT;
+        for (int k = 0; k < HELPER_OUT; k++) out[k] = 0;
+        Path p;
+        Record rec;
+        path_init(&p, &rec);
+        v3 nrm = V3(0, 0, 0);
+        float u = 0, v = 0;
+        switch (which) {
+            case 0: case 1: {
+                Box b = {in[0], in[1], in[2], in[3], in[4], in[5]};
+                out[0] = which == 0 ? box_quick(&b, ld3(in + 6), rcp3v(ld3(in + 9))) : box_exit(&b, ld3(in + 6), rcp3v(ld3(in + 9)));
+                break;
+            }
+            case 2: case 3: {
+                Box unit = {0, 1, 0, 1, 0, 1}, b = {in[0], in[1], in[2], in[3], in[4], in[5]};
+                out[0] = which == 2 ? box_full(&unit, ld3(in + 6), ld3(in + 9), rcp3v(ld3(in + 12)), &nrm, &u, &v, 0)
+                                    : box_full(&b, ld3(in + 6), ld3(in + 9), rcp3v(ld3(in + 9)), &nrm, &u, &v, 1);
+                out[1] = nrm.x; out[2] = nrm.y; out[3] = nrm.z; out[4] = u; out[5] = v;
+                break;
+            }
+            case 4: {
+                out[0] = intersect_block(s, f2i(in[0]), (int)in[1], (int)in[2], (int)in[3], &rec, ld3(in + 4), ld3(in + 7), rcp3v(ld3(in + 7)));
+                out[1] = rec.normal.x; out[2] = rec.normal.y; out[3] = rec.normal.z;
+                out[4] = rec.color.x; out[5] = rec.color.y; out[6] = rec.color.z; out[7] = rec.color.w;
+                out[8] = rec.emittance;
+                break;
+            }
+            case 6: {
+                int32_t tri[20];
+                memcpy(tri, in, sizeof tri);
+                int mat = 0;
+                out[0] = triangle_hit(tri, in[26], ld3(in + 20), ld3(in + 23), &nrm, &u, &v, &mat);
+                out[1] = nrm.x; out[2] = nrm.y; out[3] = nrm.z; out[4] = u; out[5] = v; out[6] = i2f(mat);
+                break;
+            }
+            case 7: {
+                unsigned state = (unsigned)f2i(in[0]);
+                rec.normal = ld3(in + 1);
+                sun_sample_direction(&sun, &p, &rec, &state);
+                out[0] = p.direction.x; out[1] = p.direction.y; out[2] = p.direction.z; out[3] = rec.emittance; out[4] = i2f((int)state);
+                break;
+            }
+            case 8: {
+                p.direction = ld3(in);
+                rec.color.x = in[3]; rec.color.y = in[4]; rec.color.z = in[5]; rec.color.w = in[6];
+                const v4 before = rec.color;
+                sun_intersect(s, &sun, &p, &rec);
+                out[0] = rec.color.x; out[1] = rec.color.y; out[2] = rec.color.z; out[3] = rec.color.w;
+                out[4] = memcmp(&before, &rec.color, sizeof before) ? 1.0f : 0.0f;  /* (the restatement returns nothing: "added" stands in) */
+                break;
+            }
+            case 9: {
+                p.direction = ld3(in);
+                sky_intersect(s, &p, &rec);
+                out[0] = rec.color.x; out[1] = rec.color.y; out[2] = rec.color.z; out[3] = rec.color.w;
+                break;
+            }
+            case 10: {
+                unsigned state = (unsigned)f2i(in[0]);
+                rec.normal = ld3(in + 1);
+                rec.point = ld3(in + 4);
+                next_path(&p, &rec, &state, 5);
+                out[0] = p.direction.x; out[1] = p.direction.y; out[2] = p.direction.z;
+                out[3] = p.origin.x; out[4] = p.origin.y; out[5] = p.origin.z; out[6] = i2f((int)state);
+                break;
+            }
+            case 11: {
+                const v4 c = atlas_read_uv(s, in[0], in[1], f2i(in[2]), f2i(in[3]));
+                out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+                break;
+            }
+            case 12: {
+                out[0] = material_sample(s, f2i(in[0]), &rec, in[1], in[2]) ? 1.0f : 0.0f;
+                out[1] = rec.color.x; out[2] = rec.color.y; out[3] = rec.color.z; out[4] = rec.color.w;
+                out[5] = rec.emittance;
+                break;
+            }
+            case 14: case 15: {
+                p.origin = ld3(in);
+                p.direction = ld3(in + 3);
+                if (which == 15) rec.distance = in[6];
+                const int hit = which == 14 ? octree_intersect(s, &p, &rec, 256) : bvh_intersect(s, s->world_bvh, &p, &rec);
+                int o = 0;
+                out[o++] = hit ? 1.0f : 0.0f;
+                out[o++] = rec.distance;
+                if (which == 14) out[o++] = i2f(rec.material);
+                out[o++] = rec.normal.x; out[o++] = rec.normal.y; out[o++] = rec.normal.z;
+                out[o++] = rec.color.x; out[o++] = rec.color.y; out[o++] = rec.color.z; out[o++] = rec.color.w;
+                out[o++] = rec.emittance;
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
 /* The three constants of the render loop (K/rayTracer.cl:94 drawDepth 256, :99 emitter factor 13, :107 ray depth 5).
  * The HIP library exposes them as options (CHUNKY_OPT_DRAW_DEPTH / _EMITTER_SCALE / _MAX_DEPTH); the checker follows
  * so that non-default values can be compared too.  Defaults = the reference. */

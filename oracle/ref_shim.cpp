@@ -395,6 +395,173 @@ int ref_trace_records(const OracleScene* s, int seed, int gid, OracleHit* out, f
     return n;
 }
 
+/* ---- helper-level known answers: the reference object's own exported helpers, one call per input row ----
+ * (tests/golden/generate.py write_helpers -> tests/golden/helpers.npz; oracle/port.c port_helpers and the device's
+ * chunky_selftest_helpers evaluate their counterparts on the same rows).  A row is HELPER_IN floats in, HELPER_OUT floats
+ * out; ints travel as their bit patterns.  which:
+ *   0 AABB_quick_intersect   in: box[0:6] o[6:9] d[9:12] (invDir = 1/d)                 out: t
+ *   1 AABB_exit              same                                                       out: t
+ *   2 AABB_full_intersect    unit box; o[6:9] dir[9:12] invDir = 1/in[12:15]            out: t n[3] uv[2]
+ *   3 AABB_full_intersect_map_2  box o dir (invDir = 1/dir)                             out: t n[3] uv[2]
+ *   4 BlockPalette_intersectBlock  block[0] cell[1:4] (ints) pos[4:7] dir[7:10]         out: t n[3] color[4] emittance
+ *   6 Triangle_new + Triangle_intersect  tri[0:20] o[20:23] dir[23:26] distance[26]     out: t n[3] uv[2] material
+ *   7 Sun_sampleDirection    state[0] normal[1:4]                                       out: dir[3] emittance state
+ *   8 Sun_intersect          d[0:3] color[3:7]                                          out: color[4] hit
+ *   9 Sky_intersect          d[0:3]                                                     out: color[4]
+ *  10 nextPath               state[0] normal[1:4] point[4:7]                            out: dir[3] origin[3] state
+ *  11 Atlas_read_uv          u v location size                                          out: color[4]
+ *  12 Material_get + Material_sample  material[0] u v                                   out: ok color[4] emittance
+ *  14 Octree_octreeIntersect o[0:3] d[3:6]                                              out: hit distance material n[3] color[4] emittance
+ *  15 Bvh_intersect (world)  o[0:3] d[3:6] distance[6]                                  out: hit distance n[3] color[4] emittance */
+#define HELPER_IN 32
+#define HELPER_OUT 12
+} /* extern "C" */
+typedef int cl_int3v __attribute__((ext_vector_type(3)));
+struct RefAABB { float xmin, xmax, ymin, ymax, zmin, zmax; };              /* primitives.h:8-15 */
+struct RefTriangle { int flags; cl_float3 e1, e2, o, n; cl_float2 t1, t2, t3; int material; };  /* primitives.h:323-333 */
+struct RefMaterial { unsigned w[6]; };                                     /* material.h:20-27 */
+static_assert(sizeof(RefAABB) == 24 && sizeof(RefTriangle) == 112 && sizeof(RefMaterial) == 24, "struct mirror out of sync");
+extern "C" {
+RefAABB AABB_new(float, float, float, float, float, float);
+float AABB_quick_intersect(RefAABB*, cl_float3, cl_float3);
+float AABB_exit(RefAABB*, cl_float3, cl_float3);
+float AABB_full_intersect(RefAABB*, cl_float3, cl_float3, cl_float3, cl_float3*, cl_float2*);
+float AABB_full_intersect_map_2(RefAABB*, cl_float3, cl_float3, cl_float3, cl_float3*, cl_float2*);
+float BlockPalette_intersectBlock(RefBlockPalette*, int, cl_int3v, RefRecord*, cl_float3, cl_float3, cl_float3, const ShimImage*);
+RefTriangle Triangle_new(const int*, int);
+float Triangle_intersect(RefTriangle*, float, cl_float3, cl_float3, cl_float3*, cl_float2*, int*);
+bool Sun_intersect(RefSun*, RefRecord*, const ShimImage*);
+void Sky_intersect(RefRecord*, const ShimImage*, float);
+cl_float4 Atlas_read_uv(float, float, int, int, const ShimImage*);
+RefMaterial Material_get(RefMatPalette*, int);
+bool Material_sample(RefMaterial*, const ShimImage*, RefRecord*, cl_float2);
+bool Octree_octreeIntersect(RefOctree*, RefRecord*, RefBlockPalette*, const ShimImage*, int);
+bool Bvh_intersect(RefBvh*, RefRecord*, const ShimImage*);
+
+static inline int f2i(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float i2f(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline cl_float3 ld3(const float* p) { return (cl_float3){p[0], p[1], p[2]}; }
+static inline cl_float3 rcp3v(cl_float3 d) { return (cl_float3){1.0f / d.x, 1.0f / d.y, 1.0f / d.z}; }
+
+void ref_helpers(const OracleScene* s, int which, int n, const float* in_rows, float* out_rows) {
+    ShimImage atlas{s->atlas, s->atlas_w, s->atlas_h, s->atlas_layers};
+    ShimImage sky{s->sky, s->sky_w, s->sky_h, 1};
+    RefMatPalette mp{s->material_palette};
+    RefOctree oct{s->octree, s->octree_depth};
+    RefBvh wb{s->world_bvh, s->bvh_trigs, &mp};
+    RefBlockPalette bp{s->block_palette, s->quad_models, s->aabb_models, &mp};
+    RefSun sun = Sun_new(s->sun);
+    for (int r = 0; r < n; r++) {
+        const float* in = in_rows + (size_t)r * HELPER_IN;
+        float* out = out_rows + (size_t)r * HELPER_OUT;
+        for (int k = 0; k < HELPER_OUT; k++) out[k] = 0;
+        RefPixel pixel;
+        pixel.index = 0;
+        pixel.color = (cl_float3){0, 0, 0};
+        pixel.throughput = (cl_float3){1, 1, 1};
+        RefRay ray;
+        std::memset(&ray, 0, sizeof ray);
+        ray.pixel = &pixel;
+        RefRecord rec;
+        std::memset(&rec, 0, sizeof rec);
+        rec.pixel = &pixel;
+        rec.ray = &ray;
+        rec.distance = rt_inf();
+        cl_float3 nrm = {0, 0, 0};
+        cl_float2 uv = {0, 0};
+        switch (which) {
+            case 0: case 1: {
+                RefAABB b = AABB_new(in[0], in[1], in[2], in[3], in[4], in[5]);
+                out[0] = which == 0 ? AABB_quick_intersect(&b, ld3(in + 6), rcp3v(ld3(in + 9))) : AABB_exit(&b, ld3(in + 6), rcp3v(ld3(in + 9)));
+                break;
+            }
+            case 2: case 3: {
+                RefAABB b = which == 2 ? AABB_new(0, 1, 0, 1, 0, 1) : AABB_new(in[0], in[1], in[2], in[3], in[4], in[5]);
+                out[0] = which == 2 ? AABB_full_intersect(&b, ld3(in + 6), ld3(in + 9), rcp3v(ld3(in + 12)), &nrm, &uv)
+                                    : AABB_full_intersect_map_2(&b, ld3(in + 6), ld3(in + 9), rcp3v(ld3(in + 9)), &nrm, &uv);
+                out[1] = nrm.x; out[2] = nrm.y; out[3] = nrm.z; out[4] = uv.x; out[5] = uv.y;
+                break;
+            }
+            case 4: {
+                ray.direction = ld3(in + 7);
+                cl_int3v cell = {(int)in[1], (int)in[2], (int)in[3]};
+                out[0] = BlockPalette_intersectBlock(&bp, f2i(in[0]), cell, &rec, ld3(in + 4), ld3(in + 7), rcp3v(ld3(in + 7)), &atlas);
+                out[1] = rec.normal.x; out[2] = rec.normal.y; out[3] = rec.normal.z;
+                for (int k = 0; k < 4; k++) out[4 + k] = rec.color[k];
+                out[8] = rec.emittance;
+                break;
+            }
+            case 6: {
+                int tri[20];
+                std::memcpy(tri, in, sizeof tri);
+                RefTriangle t = Triangle_new(tri, 0);
+                int mat = 0;
+                out[0] = Triangle_intersect(&t, in[26], ld3(in + 20), ld3(in + 23), &nrm, &uv, &mat);
+                out[1] = nrm.x; out[2] = nrm.y; out[3] = nrm.z; out[4] = uv.x; out[5] = uv.y; out[6] = i2f(mat);
+                break;
+            }
+            case 7: {
+                unsigned state = (unsigned)f2i(in[0]);
+                rec.normal = ld3(in + 1);
+                Sun_sampleDirection(&sun, &rec, &state);
+                out[0] = ray.direction.x; out[1] = ray.direction.y; out[2] = ray.direction.z; out[3] = rec.emittance; out[4] = i2f((int)state);
+                break;
+            }
+            case 8: {
+                ray.direction = ld3(in);
+                rec.color = (cl_float4){in[3], in[4], in[5], in[6]};
+                const bool hit = Sun_intersect(&sun, &rec, &atlas);
+                for (int k = 0; k < 4; k++) out[k] = rec.color[k];
+                out[4] = hit ? 1.0f : 0.0f;
+                break;
+            }
+            case 9: {
+                ray.direction = ld3(in);
+                Sky_intersect(&rec, &sky, s->sky_intensity);
+                for (int k = 0; k < 4; k++) out[k] = rec.color[k];
+                break;
+            }
+            case 10: {
+                unsigned state = (unsigned)f2i(in[0]);
+                rec.normal = ld3(in + 1);
+                rec.point = ld3(in + 4);
+                nextPath(&rec, &state, 5);
+                out[0] = ray.direction.x; out[1] = ray.direction.y; out[2] = ray.direction.z;
+                out[3] = ray.origin.x; out[4] = ray.origin.y; out[5] = ray.origin.z; out[6] = i2f((int)state);
+                break;
+            }
+            case 11: {
+                cl_float4 c = Atlas_read_uv(in[0], in[1], f2i(in[2]), f2i(in[3]), &atlas);
+                for (int k = 0; k < 4; k++) out[k] = c[k];
+                break;
+            }
+            case 12: {
+                RefMaterial m = Material_get(&mp, f2i(in[0]));
+                const bool ok = Material_sample(&m, &atlas, &rec, (cl_float2){in[1], in[2]});
+                out[0] = ok ? 1.0f : 0.0f;
+                for (int k = 0; k < 4; k++) out[1 + k] = rec.color[k];
+                out[5] = rec.emittance;
+                break;
+            }
+            case 14: case 15: {
+                ray.origin = ld3(in);
+                ray.direction = ld3(in + 3);
+                if (which == 15) rec.distance = in[6];
+                const bool hit = which == 14 ? Octree_octreeIntersect(&oct, &rec, &bp, &atlas, 256) : Bvh_intersect(&wb, &rec, &atlas);
+                int o = 0;
+                out[o++] = hit ? 1.0f : 0.0f;
+                out[o++] = rec.distance;
+                if (which == 14) out[o++] = i2f(rec.material);
+                out[o++] = rec.normal.x; out[o++] = rec.normal.y; out[o++] = rec.normal.z;
+                for (int k = 0; k < 4; k++) out[o++] = rec.color[k];
+                out[o++] = rec.emittance;
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
 /* ---- known-answer helpers ---- */
 void ref_pcg_stream(unsigned state, int n, unsigned* states, float* floats) {
     for (int i = 0; i < n; i++) {

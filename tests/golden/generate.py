@@ -10,6 +10,8 @@ kats.npz holds the function-level known answers (PCG stream, seed stream, sun ba
 filter.npz (`python tests/golden/generate.py filter` writes only this one) holds the reference tone-map
 kernel (tonemap/include/post_processing_filter.cl, compiled in place the same way): sample values,
 exposures, and the ARGB words for every filter type, plus pow known answers.
+timed_rows.npz (`... generate.py timed`): rows of the five BASELINE views at their timed sizes (write_timed).
+helpers.npz (`... generate.py helpers`): known answers of the reference's exported helper functions (write_helpers).
 """
 import os
 import sys
@@ -49,11 +51,50 @@ def write_filter(ref):
     print("filter written", out.shape)
 
 
+def write_timed(ref):
+    """timed_rows.npz: whole image rows of the BASELINE views AT THE SIZES THAT ARE TIMED (golden_scenes.timed_view), rendered
+    by the reference build — TIMED_PASSES passes of the java.util.Random(0) seed stream — so that parity at depth-9/10 octrees
+    and height-17 BVHs does not rest on the C restatement."""
+    seeds = scenes.java_random_ints(gs.TIMED_PASSES)
+    out = {"seeds": seeds}
+    for name in gs.TIMED_VIEWS:
+        sc = gs.timed_view(name)
+        h = binding.SceneHandle(sc)
+        rows = gs.timed_rows(sc)
+        res = np.zeros((len(rows), sc.width, 3), np.float32)
+        for k, y in enumerate(rows):
+            full = ref.render_passes(h, seeds, gid_range=(y * sc.width, (y + 1) * sc.width), threads=8)
+            res[k] = full.reshape(-1, 3)[y * sc.width:(y + 1) * sc.width]
+        out[name + "_digest"] = gs.input_digest(sc)
+        out[name + "_rows"] = np.array(rows, np.int32)
+        out[name + "_res"] = res
+        print(name, sc.width, sc.height, "rows", rows, "mean", float(res.mean()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "timed_rows.npz"), **out)
+
+
+def write_helpers(ref):
+    """helpers.npz: answers of the reference object's own exported helpers (oracle/ref_shim.cpp ref_helpers drives them) on the
+    input rows of golden_scenes.helper_rows, for the golden scene "entities" (models, textures, sun disc, both BVHs)."""
+    sc = gs.make(gs.HELPER_SCENE)
+    out = {"digest": gs.input_digest(sc)}
+    for which in gs.HELPER_KINDS:
+        rows = gs.helper_rows(sc, which)
+        out[f"in{which}_sha256"] = gs.rows_digest(rows)   # the rows are regenerated from their seeds by the tests
+        out[f"out{which}"] = ref.helpers(sc, which, rows)
+        ok = out[f"out{which}"]
+        print("helper", which, rows.shape, "finite first column:", float(np.isfinite(ok[:, 0]).mean()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
+
+
 def main():
     ref = binding.ref()
     assert ref is not None, "needs /root/reference"
     if "filter" in sys.argv[1:]:
         return write_filter(ref)
+    if "timed" in sys.argv[1:]:
+        return write_timed(ref)
+    if "helpers" in sys.argv[1:]:
+        return write_helpers(ref)
     seeds = scenes.java_random_ints(gs.N_PASSES)
     for name in gs.NAMES:
         sc = gs.make(name)
@@ -86,6 +127,8 @@ def main():
         atan2=ref.math(4, ya, xa), fmod1=ref.math(5, xs), sun=sun, sun_basis=ref.sun_basis(sun))
     print("kats written")
     write_filter(ref)
+    write_timed(ref)
+    write_helpers(ref)
 
 
 if __name__ == "__main__":

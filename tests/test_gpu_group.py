@@ -94,7 +94,7 @@ def test_group_host_loop(group3, port):
 
 
 def test_group_inside_an_outer_shard(gpu_instance, port):
-    """A group that is itself rank 1 of 2 (chunky_render_set_shard on the group): its members render as ranks 2 and 3 of 4;
+    """A group that is itself rank 1 of 2 (chunky_render_set_shard on the group): its members render as ranks 1 and 3 of 4;
     with a plain context as rank 0 of 2 the two halves add up to the whole image."""
     sc = scenes.outdoor_world(chunks=4, height=64, seed=12, width=160, img_height=96, aabb_frac=0.05, quad_frac=0.03)
     seeds = native.java_random_ints(3)

@@ -435,3 +435,21 @@ def test_full_size_properties(gpu_instance):
     np.testing.assert_array_equal(bits(total), bits(a))
     r.close()
     loader.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 8])
+def test_aabb_plus_z_face_on_the_device(gpu_instance, port, variant):
+    """+z faces of AABB models read an unset material in the reference (K/primitives.h:209-234); the reference build takes the
+    EAST material (tests/test_oracle_pinning.py::test_aabb_plus_z_face pins that against the reference object).  The HIP
+    kernels must do the same — through the aligned model records (default) and through the packed palettes (variant bit 0) —
+    in the hit record and in the rendered image."""
+    sc = gs.plus_z_scene()
+    loader, r = make_renderer(gpu_instance, sc, variant)
+    rec, cnt, _rad = r.trace_records(1, [gs.PLUS_Z_GID])
+    assert cnt[0] >= 1 and rec[0, 0]["hit"] == 1 and rec[0, 0]["normal"].tolist() == [0, 0, 1]
+    np.testing.assert_array_equal(rec[0, 0]["color"], gs.PLUS_Z_EAST)
+    seeds = scenes.java_random_ints(6)
+    r.render_passes(seeds)
+    assert_radiance(r.read(), port.render_passes(sc, seeds), f"+z face image, variant {variant}")
+    r.close()
+    loader.close()

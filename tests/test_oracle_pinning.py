@@ -86,26 +86,21 @@ def test_aabb_plus_z_face(port, ref):
     """+z faces of AABB models read an unset material in the reference (K/primitives.h:209-234).
     The -O2 reference build resolves it to the EAST material; port.c and the HIP kernels adopt
     exactly that, so this case needs no mask."""
-    pal = scenes.Palettes()
-    cols = [0xFFFF0000, 0xFF00FF00, 0xFF0000FF, 0xFFFFFF00, 0xFFFF00FF, 0xFF00FFFF]
-    mats = [pal.material(argb=c) for c in cols]
-    pal.block_invisible()
-    blk = pal.block_aabbs([((0.25, 0.75, 0.25, 0.75, 0.25, 0.75), 0, tuple(mats))])
-    t = np.zeros((8, 8, 8), np.int32)
-    t[4, 4, 4] = blk
-    b, m, a, q = pal.arrays()
-    sc = scenes.PackedScene(octree=scenes.build_octree(t, 3), octree_depth=3, block_palette=b, material_palette=m,
-                            aabb_models=a, quad_models=q, world_bvh=scenes.empty_bvh(), actor_bvh=scenes.empty_bvh(),
-                            bvh_trigs=np.zeros(1, np.int32), atlas=np.zeros((1, 16, 16, 4), np.uint8),
-                            sky=scenes.bake_sky(16), sky_intensity=1.0, sun=scenes.pack_sun(0.6, 1.2, 1.0, False),
-                            camera=scenes.look_at_camera((4.5, 4.5, 7.5), (4.5, 4.5, 4.5), 40.0), width=9, height=9)
+    sc = gs.plus_z_scene()
     gid = 4 * 9 + 4
     hr, _ = ref.trace_records(sc, 1, gid)
     hp, _ = port.trace_records(sc, 1, gid)
     assert hr[0]["hit"] == 1 and hr[0]["normal"].tolist() == [0, 0, 1]
-    east = np.array([0, 255 / 256, 0, 255 / 256], np.float32)
-    np.testing.assert_array_equal(hr[0]["color"], east)
-    np.testing.assert_array_equal(hp[0]["color"], east)
+    np.testing.assert_array_equal(hr[0]["color"], gs.PLUS_Z_EAST)
+    np.testing.assert_array_equal(hp[0]["color"], gs.PLUS_Z_EAST)
+
+
+def test_aabb_plus_z_face_restatement(port):
+    """The same answer from the restatement alone (runs where the reference build is absent: the committed constant
+    gs.PLUS_Z_EAST is what the reference build returned)."""
+    hp, _ = port.trace_records(gs.plus_z_scene(), 1, gs.PLUS_Z_GID)
+    assert hp[0]["hit"] == 1 and hp[0]["normal"].tolist() == [0, 0, 1]
+    np.testing.assert_array_equal(hp[0]["color"], gs.PLUS_Z_EAST)
 
 
 def test_access_stream_counters(port):

@@ -4,6 +4,7 @@
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 (cd $R && python3 -c 'from chunkyclplugin_amd import native; native.build(); native.lib(); from oracle import binding; binding.port()') || exit 1
+export CHUNKY_ORACLE_NO_BUILD=1   # nothing is compiled or spawned from inside the profiled process
 cd /tmp && export TMPDIR=/tmp
 (cd $R && timeout ${KT_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 "$@" > $O/kt.log 2>&1 < /dev/null)
 cd $R

@@ -10,7 +10,8 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 # build everything BEFORE the profiler is attached: nothing may compile or spawn a child from inside a profiled process
 # (with --pmc the profiler's preloaded library initialises the GPU in every child, and a child that then execs is refused)
-(cd $R && python3 -c 'from chunkyclplugin_amd import native; native.build(); native.lib()') || exit 1
+(cd $R && python3 -c 'from chunkyclplugin_amd import native; native.build(); native.lib(); from oracle import binding; binding.port()') || exit 1
+export CHUNKY_ORACLE_NO_BUILD=1   # the profiled process (and tools/config_bench.py's oracle check in it) never spawns make
 cd /tmp && export TMPDIR=/tmp
 declare -A G
 G[sq1]="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
