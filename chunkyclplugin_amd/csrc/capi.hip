@@ -78,7 +78,7 @@ struct DevBuf {
 
 struct chunky_scene {
     chunky_ctx* ctx = nullptr;
-    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, cube_info, quad_aux;
+    DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, quad_aux;
     DevBuf mat8, aabb_rec, quad_rec;                   // 16-byte-aligned re-layouts of the palettes (rt_device.hpp)
     DevBuf bvh_rec, tri_rec;                           // both entity BVHs as 64-byte inner nodes, triangles as 80-byte records
     DevBuf emitters;                                   // emitter next-event estimation: {x, y, z, level << 25 | block} per emitter leaf
@@ -88,7 +88,7 @@ struct chunky_scene {
     int world_root = 0, actor_root = 0;                // first reference of each BVH in bvh_rec / tri_rec (rt_device.hpp)
     bool bvh_dirty = false;
     std::vector<int32_t> host_blocks, host_materials, host_aabbs, host_quads;  // kept to rebuild what is derived from them
-    bool derived_dirty = false;                        // block_info, cube_info, quad_aux, mat8, aabb_rec, quad_rec
+    bool derived_dirty = false;                        // block_info, quad_aux, mat8, aabb_rec, quad_rec
     WideTree wide_meta;  // host copy kept so the kind bits can follow the block palette; nlev == 0 when absent
     bool wide_dirty = false;
     int octree_depth = -1;
@@ -556,7 +556,6 @@ static bool build_quad_aux(const std::vector<int32_t>& B, const std::vector<int3
 
 // Everything the kernels read that is derived from the four palettes (rt_device.hpp has the layouts):
 //   block_info  per block {type, pointer, 5 material words of a full cube, model record}
-//   cube_info   per block the 16 bytes of the full-cube test
 //   mat8        materials at a 32-byte stride (two 16-byte reads instead of five unaligned dwords)
 //   aabb_rec    AABB-model boxes as three 16-byte words each, materials as mat8 indices
 //   quad_rec    quad-model quads as six 16-byte words each (the material's five words inline), with the ray-independent values of K/primitives.h:262-276
@@ -568,7 +567,6 @@ static int rebuild_derived(chunky_scene* s) {
     hipStream_t st = s->ctx->stream;
     HIP_TRY(hipStreamSynchronize(st));  // queued passes may still read the old copies
     s->block_info.release();
-    s->cube_info.release();
     s->quad_aux.release();
     s->mat8.release();
     s->aabb_rec.release();
@@ -585,7 +583,6 @@ static int rebuild_derived(chunky_scene* s) {
         return true;
     };
     std::vector<int32_t> info(n_blocks * 8, 0), aabb_rec, quad_rec;
-    std::vector<uint32_t> cube(n_blocks * 4, 0u);
     std::vector<int64_t> aabb_at(A.size(), -1), quad_at(Q.size(), -1);  // model pointer -> first record (models are shared between blocks)
     for (size_t k = 0; k < n_blocks; k++) {
         int32_t* e = &info[k * 8];
@@ -596,13 +593,6 @@ static int rebuild_derived(chunky_scene* s) {
             if (ptr >= 0 && (size_t)ptr + 5 <= M.size()) {
                 for (int w = 0; w < 5; w++) e[2 + w] = M[(size_t)ptr + w];
                 if ((size_t)ptr + 6 <= M.size()) e[7] = M[(size_t)ptr + 5];  // material word 5 (extensions)
-                if (!(e[2] & 2)) {  // no emittance texture: the 16-byte form carries everything
-                    uint32_t* c = &cube[k * 4];
-                    c[0] = 0x80000000u | (((uint32_t)e[6] & 0xFFu) << 8) | ((uint32_t)e[2] & 7u);
-                    c[1] = (uint32_t)e[3];
-                    c[2] = (uint32_t)e[4];
-                    c[3] = (uint32_t)e[5];
-                }
             } else {
                 e[0] = 0x7FFFFFFF;  // malformed cube: an unknown model type never hits (K/block.h:44-47)
             }
@@ -672,7 +662,6 @@ static int rebuild_derived(chunky_scene* s) {
         }
     }
     HIP_TRY(s->block_info.upload(info.data(), info.size() * 4, st));
-    HIP_TRY(s->cube_info.upload(cube.data(), cube.size() * 4, st));
     HIP_TRY(s->mat8.upload(mat8.data(), mat8.size() * 4, st));
     if (!aabb_rec.empty()) HIP_TRY(s->aabb_rec.upload(aabb_rec.data(), aabb_rec.size() * 4, st));
     if (!quad_rec.empty()) HIP_TRY(s->quad_rec.upload(quad_rec.data(), quad_rec.size() * 4, st));
@@ -878,7 +867,6 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     v->quad_aux = (const float*)s->quad_aux.p;
     v->bvh_stack_entries = (s->world_height > s->actor_height ? s->world_height : s->actor_height) + 1;
     v->block_info = (const int4*)s->block_info.p;
-    v->cube_info = (const uint4*)s->cube_info.p;
     v->mat8 = (const int4*)s->mat8.p;
     v->aabb_rec = (const int4*)s->aabb_rec.p;
     v->quad_rec = (const int4*)s->quad_rec.p;
@@ -958,7 +946,7 @@ extern "C" int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int wi
     r->own_fb.bytes = bytes;
     r->fb = (float*)r->own_fb.p;
     HIP_TRY(hipMemsetAsync(r->fb, 0, bytes, ctx->stream));
-    // [0] the sample / pixel queue, [2..49] the phase profile, [64..127] render_pool's range counters (kernels.hip xcd_claim)
+    // [0] the sample / pixel queue, [2..49] the phase profile, [64..127] render_pool's range counters (render_pool.hip xcd_claim)
     HIP_TRY(hipMalloc(&r->work_counter.p, 512));
     r->work_counter.bytes = 512;
     HIP_TRY(hipMemsetAsync(r->work_counter.p, 0, 512, ctx->stream));

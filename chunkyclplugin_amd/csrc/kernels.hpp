@@ -1,4 +1,5 @@
-// kernels.hpp — host-visible launch interface of kernels.hip.
+// kernels.hpp — host-visible launch interface of the kernel translation units (render_pool.hip, render_fallback.hip,
+// aux_kernels.hip, filter.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,7 +50,7 @@ struct KernelChoice {
     int ext;     // the extended integrator (CHUNKY_OPT_SUN_SAMPLING / _EMITTERS / _BSDF / _EMITTER_NEE at non-default values)
 };
 // render_pool's tiles of 256 pixel slots: the image's 16 x 16-pixel blocks with one rank (edge blocks padded), the rank's own
-// blocks or 256-slot runs with several (kernels.hip pool_slot_gid)
+// blocks or 256-slot runs with several (path_state.hpp pool_slot_gid)
 inline long long pool_tile_count(const ShardView& T, int width, int height) {
     if (T.world != 1) return ((long long)T.n_local + 255) / 256;
     return (long long)((width + 15) / 16) * ((height + 15) / 16);
@@ -62,6 +63,9 @@ inline size_t staging_floats(const ShardView& T, int width, int height, int n_pa
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream,
                          KernelChoice* chosen = nullptr, float* staging = nullptr);
+// the kernels behind render_pool (render_fallback.hip): render_waves, render_lanes
+hipError_t launch_fallback(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
+                           const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen);
 // read-back exchange of a multi-GPU group: pack = true copies the pixels of this shard's slots from the image `fb` to `packed`
 // (3 floats per slot, padding slots skipped), pack = false scatters them back into an image
 hipError_t launch_gather(bool pack, const ShardView& T, int width, int height, float* fb, float* packed, hipStream_t stream);
@@ -77,7 +81,7 @@ hipError_t launch_filter(long long n_pixels, float exposure, const double* in, u
 // threshold table, for `count` consecutive float bit patterns
 hipError_t launch_gamma_scan(unsigned first, unsigned long long count, int curve, const float* thresholds, unsigned long long* mismatches,
                              float* worst, hipStream_t stream);
-// helper-level known answers (kernels.hip helpers_selftest_kernel): rows of 32 floats in, 12 out
+// helper-level known answers (aux_kernels.hip helpers_selftest_kernel): rows of 32 floats in, 12 out
 hipError_t launch_helpers_selftest(const SceneView& S, int which, int tree, int n, const float* in, float* out, int* tree_used, hipStream_t stream);
 hipError_t launch_math_selftest(int which, int n, const float* a, const float* b, float* out, hipStream_t stream);
 

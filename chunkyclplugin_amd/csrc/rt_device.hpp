@@ -7,7 +7,7 @@
 // translation unit is compiled with -ffp-contract=off.
 //
 // Nothing here mirrors the reference's control flow: the helpers are leaf computations that the
-// kernels in kernels.hip schedule per wavefront.
+// kernels in render_pool.hip / render_fallback.hip schedule per wavefront.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -77,10 +77,6 @@ struct SceneView {
     // per quad, at the quad's own int offset in `quads`: {normal xyz, dot(normal, origin), |xv|^2, |yv|^2} — the
     // ray-independent part of K/primitives.h:262-276, evaluated once at upload with this same rt_math.h; null = compute
     const float* __restrict__ quad_aux;
-    // per block (index = block pointer / 2) 16 bytes for the full-cube test: {valid << 31 | (emittance byte) << 8 | material
-    // flags, tint, textureSize, color} — K/block.h:48-65 with K/material.h:31-40 as ONE 16-byte read.  valid = 0 for
-    // blocks that are not well-formed cubes or whose material uses an emittance texture (those take the general path).
-    const uint4* __restrict__ cube_info;
     // 16-byte-aligned re-layouts built at upload (capi.hip rebuild_derived); block_info word 7 of a model block =
     // first record << 8 | primitive count, 0 = none (the packed palettes are read as they are):
     //   mat8      per material two words {flags, tint, textureSize, color} {normal_emittance, word 5, 0, 0}
@@ -438,15 +434,6 @@ DEV float block_hit(const SceneView& S, int block, int bx, int by, int bz, f3 po
         case 3: return quad_model_hit(S, ptr, no, dir, h);
         default: return rt_nan();
     }
-}
-
-// The same for a candidate the tree marks as a full cube (leaf kind 0, widetree.hpp): only the cube branch of
-// K/block.h:48-65.  A malformed cube entry carries an unknown model type in block_info and misses, as there.
-DEV float block_hit_cube(const SceneView& S, int block, int bx, int by, int bz, f3 pos, f3 dir, f3 inv, Hit& h) {
-    const uint4 c = S.cube_info[(unsigned)block >> 1];
-    if (!(c.x & 0x80000000u)) return block_hit(S, block, bx, by, bz, pos, dir, inv, h);
-    const f3 no = (pos - dir * kOffset) - mk3((float)bx, (float)by, (float)bz);
-    return cube_hit(S, c.x & 7u, c.y, c.z, c.w, (c.x >> 8) & 0xFFu, no, pos, inv, h);
 }
 
 // ---------------------------------------------------------------------------------------------

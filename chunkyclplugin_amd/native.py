@@ -18,7 +18,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("CHUNKY_HIP_LIB") or os.path.join(PKG_DIR, "libchunky_hip.so")  # override: tuning builds (tools/variants.sh)
 HEADER = os.path.join(os.path.dirname(PKG_DIR), "include", "chunky_hip.h")
-SOURCES = ["kernels.hip", "capi.hip", "widetree.cpp"]
+SOURCES = ["render_pool.hip", "render_fallback.hip", "aux_kernels.hip", "filter.hip", "capi.hip", "widetree.cpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 MAX_TRACES = 10
@@ -50,14 +50,29 @@ def _needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False) -> str:
+def build(force: bool = False, extra_flags=(), out: Optional[str] = None, objdir: Optional[str] = None) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     if force or _needs_build():
-        cmd = ["hipcc", *HIPCC_FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
-        proc = subprocess.run(cmd, capture_output=True, text=True)
+        # one hipcc per translation unit, side by side (objects under csrc/build/, git-ignored), then one link
+        from concurrent.futures import ThreadPoolExecutor
+        objdir = objdir or os.path.join(CSRC, "build")
+        os.makedirs(objdir, exist_ok=True)
+        flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+
+        def compile_one(src):
+            obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            cmd = ["hipcc", *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+            proc = subprocess.run(cmd, capture_output=True, text=True)
+            if proc.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n" + proc.stderr[-4000:])
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        proc = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out or LIB_PATH], capture_output=True, text=True)
         if proc.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + proc.stderr[-4000:])
-    return LIB_PATH
+            raise RuntimeError("hipcc link failed:\n" + proc.stderr[-4000:])
+    return out or LIB_PATH
 
 
 def declared_symbols() -> List[str]:

@@ -6,7 +6,7 @@ The reference is single-device; this is new.  One process per GPU (torch.distrib
 * the image is cut into tiles — blocks of 16 x 16 pixels (`tile` 0, the default of bench.py: the shape
   the pool kernel renders in) or runs of `tile` consecutive pixel indices; tile t belongs to rank
   t % world (`chunky_render_set_shard` applies the same rule on the device: `pool_slot_gid` /
-  `shard_gid` in csrc/kernels.hip);
+  `shard_gid` in csrc/path_state.hpp);
 * every rank renders into a full-size framebuffer that stays zero outside its own tiles;
 * ONE collective per read-back: `reduce(SUM)` to rank 0.  Tiles are disjoint and x + 0 = x exactly,
   so the result is bit-identical to the 1-GPU image.  Nothing is exchanged per pass.

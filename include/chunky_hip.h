@@ -115,10 +115,11 @@ typedef enum chunky_option {
     CHUNKY_OPT_DRAW_DEPTH = 0,      /* int, default 256  (K/rayTracer.cl:94) */
     CHUNKY_OPT_MAX_DEPTH = 1,       /* int >= 1, default 5 (K/rayTracer.cl:107) */
     CHUNKY_OPT_EMITTER_SCALE = 2,   /* float bits, default 13.0f (K/rayTracer.cl:99) */
-    CHUNKY_OPT_KERNEL = 3,          /* int: kernel variant, 0 = default; bit 0 reference octree layout, bit 1 one lane
-                                     * per path, bit 2 phase profile, bit 3 the grouped kernel instead of the pool kernel,
-                                     * bits 4-5 (grouped kernel) lanes per pixel 1/8/16, bits 6-7 (pool kernel) paths parked
-                                     * per wave none/32/64 instead of 56 (all bit-identical) */
+    CHUNKY_OPT_KERNEL = 3,          /* int: kernel variant, 0 = default (the pool kernel); bit 0 reference octree layout, bit 1
+                                     * one lane per path (render_lanes), bit 2 phase profile (pool kernel), bit 3 the
+                                     * fallback kernel render_waves instead of the pool kernel, bits 4-5 (render_waves)
+                                     * lanes per pixel 1/8/16, bits 6-7 (pool kernel) paths parked per wave none/32 instead
+                                     * of 56 (all bit-identical) */
     /* EXPERIMENTAL light-transport extensions (the reference has none of them — it gates sun
      * sampling on drawTexture, PackedSun.java:16 / K/sky.h:69, ignores emittersEnabled, and loads material word 5 without
      * using it, K/material.h:38).  Specification: oracle/port.c trace_sample_ext; DESIGN.md section 9.  The defaults are the

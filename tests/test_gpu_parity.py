@@ -36,9 +36,9 @@ def assert_radiance(got, want, what):
 
 # CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (render_pool, 56 parked paths per wave, wide-tree
 # lookup), bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes),
-# bit 3 = the grouped kernel render_waves (always used for scenes with entity BVHs) with bits 4-5 = its lanes per pixel
-# forced to 1 / 8 / 16, bits 6-7 = render_pool with no / 32 / 64 parked paths
-VARIANTS = [0, 1, 2, 3, 64, 128, 192, 8, 9, 8 | 16, 8 | 32, 8 | 48]
+# bit 3 = the fallback kernel render_waves (bits 4-5 = its lanes per pixel forced to 1 / 8 / 16: test_pixel_groups covers them
+# all), bits 6-7 = render_pool with no / 32 parked paths
+VARIANTS = [0, 1, 2, 3, 64, 128, 8, 9, 8 | 16]
 
 
 def make_renderer(gpu_instance, sc, variant=0):
@@ -186,20 +186,16 @@ def test_launch_chunking_is_invisible(gpu_instance, port):
     loader.close()
 
 
-@pytest.mark.parametrize("group", [1, 8, 16, 32])
-def test_every_group_size_gives_the_same_image(gpu_instance, port, group):
-    """Lanes per pixel (CHUNKY_DEBUG_GROUP forces it) only changes who computes which pass: 64 passes, bit-identical."""
-    import os
+@pytest.mark.parametrize("group,variant", [(1, 8 | 16), (8, 8 | 32), (16, 8 | 48), (32, 8)])
+def test_every_group_size_gives_the_same_image(gpu_instance, port, group, variant):
+    """render_waves' lanes per pixel (variant bits 4-5 force 1 / 8 / 16; a small image with 64 passes gets 32 by itself) only
+    changes who computes which pass: bit-identical."""
     sc = gs.make("outdoor").with_view(96, 54)
     seeds = scenes.java_random_ints(64)
-    loader, r = make_renderer(gpu_instance, sc, variant=8)
-    os.environ["CHUNKY_DEBUG_GROUP"] = str(group)
-    try:
-        r.render_passes(seeds)
-        got = r.read()
-    finally:
-        del os.environ["CHUNKY_DEBUG_GROUP"]
-    assert_radiance(got, port.render_passes(sc, seeds), f"group {group}")
+    loader, r = make_renderer(gpu_instance, sc, variant=variant)
+    r.render_passes(seeds)
+    assert r.kernel_info()["group"] == group and r.kernel_info()["pool"] < 0, r.kernel_info()
+    assert_radiance(r.read(), port.render_passes(sc, seeds), f"group {group}")
     r.close()
     loader.close()
 

@@ -91,7 +91,7 @@ def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group,
     if variant == 0:
         assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
     else:
-        assert (info["tree"], info["group"], info["bvh"], info["pool"]) == (17, group, False, -1), info
+        assert (info["tree"], info["group"], info["bvh"], info["pool"]) == (-1, group, False, -1), info   # the fallback: generic tree form
     own = parallel.owned_gids(sc.width * sc.height, rank, world, 256)
     rows = row_gids(sc)
     mine = np.intersect1d(rows, own)
@@ -219,7 +219,7 @@ def entity_world(outdoor):
 @pytest.mark.parametrize("world,passes,group,variant", [(1, 16, 0, 0), (4, 32, 0, 0), (1, 16, 8, 8), (4, 32, 16, 8)])
 def test_entity_kernels(gpu_instance, port, entity_world, world, passes, group, variant):
     """The 100 k-triangle world (BVHs of height ~17, both BVHs walked): render_pool<17, 16 | 32, bvh> on the aligned
-    node / triangle records (default), and render_waves<17, false, 8 | 16, true> on the packed arrays (variant 8)."""
+    node / triangle records (default), and the fallback render_waves<-1, 8 | 16, true> on the packed arrays (variant 8)."""
     sc = entity_world
     seeds = native.java_random_ints(passes)
     loader, r = make(gpu_instance, sc)
@@ -231,7 +231,7 @@ def test_entity_kernels(gpu_instance, port, entity_world, world, passes, group, 
     if variant == 0:
         assert (info["tree"], info["bvh"]) == (17, True) and info["pool"] in (16, 32), info
     else:
-        assert (info["tree"], info["group"], info["bvh"], info["pool"]) == (17, group, True, -1), info
+        assert (info["tree"], info["group"], info["bvh"], info["pool"]) == (-1, group, True, -1), info
     own = parallel.owned_gids(sc.width * sc.height, rank, world, 256)
     mine = np.intersect1d(row_gids(sc, (101, 411, 540, 799, 1003)), own)
     compare_rows(r, port, sc, seeds, mine, f"entities share 1/{world}")

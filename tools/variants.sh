@@ -6,8 +6,10 @@ cd "$(dirname "$0")/.."
 mkdir -p .variants
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared $flags \
-      chunkyclplugin_amd/csrc/kernels.hip chunkyclplugin_amd/csrc/capi.hip chunkyclplugin_amd/csrc/widetree.cpp \
-      -o .variants/libchunky_hip_$name.so && echo built $name ) &
+  python3 - "$name" $flags <<'PY'
+import sys
+from chunkyclplugin_amd import native
+name, flags = sys.argv[1], sys.argv[2:]
+print("built", native.build(force=True, extra_flags=flags, out=f".variants/libchunky_hip_{name}.so", objdir=f".variants/obj_{name}"))
+PY
 done
-wait
