@@ -25,6 +25,9 @@ The JSON line also carries:
                  (PMC FETCH_SIZE x2 + WRITE_SIZE per launch) and `valu` (VALU issue share and lane utilisation — the
                  real limiter) come from the committed PMC summary named in `pmc_source` and are attached only when
                  that summary was collected for the kernel / launch shape of this run; otherwise they are null.
+                 `limits` (same source, same condition) is the steering metric: valu_lane_frac = VALU issue share x lane
+                 utilisation, the L1's tag look-ups per cycle, L2 request bandwidth against its peak, the wait share, and the
+                 limiter they add up to — `frac` itself is saturated by the cache-resident scene and ranks nothing.
   per_rank     — N > 1: every rank's kernel milliseconds (HIP events) and the milliseconds of the read-back reduce.
   cpu_baseline — the C restatement of the reference kernel (oracle/port.c, kind "port") timed on
                  this box's host cores on a bounded row-sample of the same workload (rank 0, N=1).
@@ -199,7 +202,7 @@ def main():
         achieved = bytes_per_sample * samples_per_launch / (launch_ms * 1e-3) / 1e9 if (launch_ms > 0 and bytes_per_sample) else 0.0
         kernel_name = ("render_pool<%d,%d>+fold_kernel" % (info["tree"], info["pool"]) if info["pool"] >= 0 else
                        "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh"))
-        traffic, valu, pmc_source = None, None, None
+        traffic, valu, pmc_source, limits = None, None, None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp):
             try:
@@ -209,6 +212,7 @@ def main():
                         and pm.get("samples_per_launch") == samples_per_launch and args.kernel == 0):
                     traffic = pm.get("hbm_bytes_per_launch")
                     valu = pm.get("valu")
+                    limits = pm.get("limits")
                     pmc_source = pm.get("source")
             except Exception:
                 traffic = None
@@ -228,7 +232,7 @@ def main():
                          "achieved_is": "algorithmic bytes of the reference access stream / launch time (SURVEY 8d), "
                                         "not physical HBM traffic: the scene is cache-resident",
                          "physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and launch_ms > 0 else None,
-                         "valu": valu, "pmc_source": pmc_source,
+                         "valu": valu, "limits": limits, "pmc_source": pmc_source,
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1) if bytes_per_sample else None,
                          "kernel": kernel_name, "launches": launches, "launch_ms": round(launch_ms, 4),
                          "samples_per_launch": samples_per_launch,

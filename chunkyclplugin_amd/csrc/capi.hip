@@ -80,7 +80,8 @@ struct chunky_scene {
     chunky_ctx* ctx = nullptr;
     DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, quad_aux;
     DevBuf mat8, aabb_rec, quad_rec;                   // 16-byte-aligned re-layouts of the palettes (rt_device.hpp)
-    DevBuf bvh_rec, tri_rec;                           // both entity BVHs as 64-byte inner nodes, triangles as 80-byte records
+    DevBuf bvh_rec;                                    // both entity BVHs as 64-byte inner nodes, then their triangles as 80-byte records
+    size_t tri_off = 0;                                // byte offset of the first triangle record in bvh_rec
     DevBuf emitters;                                   // emitter next-event estimation: {x, y, z, level << 25 | block} per emitter leaf
     std::vector<int32_t> host_octree, host_emitters;
     bool emitters_dirty = true;
@@ -728,7 +729,7 @@ static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_r
                 const int64_t a = at + 7, b = head;
                 if ((size_t)a + 7 > N.size() || b < 0 || (size_t)b + 7 > N.size()) return false;
                 const int64_t idx = (int64_t)bvh_rec->size() / 16;
-                if (idx >= (1 << 30)) return false;
+                if (idx >= (1 << 24)) return false;  // (with at most 2^24 triangles: every record within 32-bit byte offsets)
                 ref = (int32_t)idx;
                 bvh_rec->resize(bvh_rec->size() + 16, 0);
                 int32_t* r = &(*bvh_rec)[(size_t)idx * 16];
@@ -846,13 +847,16 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     if (s->bvh_dirty) {
         HIP_TRY(hipStreamSynchronize(s->ctx->stream));
         s->bvh_rec.release();
-        s->tri_rec.release();
+        s->tri_off = 0;
         std::vector<int32_t> nodes, tris;
         if ((!s->world_empty || !s->actor_empty) && build_bvh_records(s, &nodes, &tris, &s->world_root, &s->actor_root)) {
             if (nodes.empty()) nodes.resize(16, 0);  // both roots are leaves
             tris.resize(tris.size() + 20, 0);        // a step at the end of the last leaf reads one record past it
+            // ONE allocation — nodes, then triangles — so the walk addresses either kind of record as a 32-bit byte offset off
+            // one scalar base (a walk longer than 2 GiB of records keeps the packed arrays: build_bvh_records' index limits)
+            s->tri_off = nodes.size() * 4;
+            nodes.insert(nodes.end(), tris.begin(), tris.end());
             HIP_TRY(s->bvh_rec.upload(nodes.data(), nodes.size() * 4, s->ctx->stream));
-            HIP_TRY(s->tri_rec.upload(tris.data(), tris.size() * 4, s->ctx->stream));
         }
         s->bvh_dirty = false;
     }
@@ -861,7 +865,8 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     v->emitters = want_emitters ? (const int4*)s->emitters.p : nullptr;
     v->n_emitters = want_emitters ? (int)(s->host_emitters.size() / 4) : 0;
     v->bvh_rec = (const int4*)s->bvh_rec.p;
-    v->tri_rec = (const int4*)s->tri_rec.p;
+    v->tri_rec = s->bvh_rec.p ? (const int4*)((const char*)s->bvh_rec.p + s->tri_off) : nullptr;
+    v->tri_off = (unsigned)s->tri_off;
     v->world_root = s->world_root;
     v->actor_root = s->actor_root;
     v->quad_aux = (const float*)s->quad_aux.p;

@@ -308,13 +308,17 @@ DEV int floor_to_int(float x) {
 // one with the plane the ray leaves through — max if inv > 0, else min — and only that one is evaluated
 // (L.far selects it; the fma is exact).  The one case where that product is NaN while the reference's fmax
 // returns the other one (p == min with inv == -inf: NaN against -inf) is restored by the fmax with -inf.
+template <bool GUARD = true>
 DEV float leaf_exit_distance(const LaneState& L, f3 far, f3 po, int bx, int by, int bz, int level) {
     const int keep = -1 << level;
     const float size = __builtin_ldexpf(1.0f, level);
     const float x0 = (float)(bx & keep), y0 = (float)(by & keep), z0 = (float)(bz & keep);
-    const float tx = rt_fmax((rt_fma(far.x, size, x0) - po.x) * L.inv.x, -rt_inf());
-    const float ty = rt_fmax((rt_fma(far.y, size, y0) - po.y) * L.inv.y, -rt_inf());
-    const float tz = rt_fmax((rt_fma(far.z, size, z0) - po.z) * L.inv.z, -rt_inf());
+    float tx = (rt_fma(far.x, size, x0) - po.x) * L.inv.x, ty = (rt_fma(far.y, size, y0) - po.y) * L.inv.y, tz = (rt_fma(far.z, size, z0) - po.z) * L.inv.z;
+    if (GUARD) {  // only a component of the direction that is exactly -0 (inv = -inf) can produce the NaN: callers that know none is may skip this
+        tx = rt_fmax(tx, -rt_inf());
+        ty = rt_fmax(ty, -rt_inf());
+        tz = rt_fmax(tz, -rt_inf());
+    }
     return rt_fmin(tx, rt_fmin(ty, tz));
 }
 // 1.0 per axis where the ray runs towards +axis: render_waves keeps it in LaneState.far, render_pool derives it from
@@ -359,7 +363,7 @@ DEV int trace_setup(const SceneView& S, LaneState& L) {
 typedef unsigned long long LaneMask;
 DEV bool in_mask(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
-template <int TREE>
+template <int TREE, bool GUARD = true>
 DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneMask marching, LaneMask& cand_out,
                     LaneMask& live_out, int& data, int& level, const LaneMask* far_masks = nullptr) {
     const int depth = S.octree_depth;
@@ -375,7 +379,7 @@ DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneM
     // render_pool passes the three lane masks "inv > 0" (scalar registers, set when the loop is entered) instead of L.far
     const f3 far = far_masks ? mk3(in_mask(far_masks[0]) ? 1.0f : 0.0f, in_mask(far_masks[1]) ? 1.0f : 0.0f, in_mask(far_masks[2]) ? 1.0f : 0.0f)
                              : L.far;
-    const float step = leaf_exit_distance(L, far, po, bx, by, bz, level) + kOffset;  // K/octree.h:103-106
+    const float step = leaf_exit_distance<GUARD>(L, far, po, bx, by, bz, level) + kOffset;  // K/octree.h:103-106
     const bool advance = in_mask(go);
     L.dist_march = advance ? L.dist_march + step : L.dist_march;
     L.steps = advance ? L.steps + 1 : L.steps;

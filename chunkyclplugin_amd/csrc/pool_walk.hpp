@@ -45,8 +45,11 @@ DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) {
     const int cur = L.bvh_cur;
     const bool inner = cur >= 0;
     const int lref = -1 - cur, tri = lref >> 6, left = lref & 63;
-    const int4* __restrict__ p = inner ? S.bvh_rec + (size_t)(unsigned)cur * 4 : S.tri_rec + (size_t)(unsigned)tri * 5;
-    const int4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+    // nodes and triangles share one allocation: a 32-bit byte offset off one scalar base, whichever the walker is at
+    const unsigned at = inner ? (unsigned)cur << 6 : S.tri_off + (unsigned)tri * 80u;
+    const int4* __restrict__ p = (const int4*)((const char*)S.bvh_rec + at);
+    const int4 r0 = p[0], r1 = p[1], r2 = p[2];
+    const int4 r3 = p[3];  // (of a triangle only a hit needs this one; fetching it for inner nodes only measured 2 % slower)
     const float limit = L.shadow ? L.bvh_dist : L.h.distance;
     if (inner) {
         const int first = r0.x, second = r0.y;

@@ -91,7 +91,8 @@ struct SceneView {
     //   tri_rec  per triangle five words {e1, flags} {e2, material (mat8 index)} {o, t1.u} {n, t1.v} {t2.u, t2.v, t3.u, t3.v}
     // A reference is an inner record's index, or -1 - (first triangle record << 6 | count) for a leaf.
     const int4* __restrict__ bvh_rec;
-    const int4* __restrict__ tri_rec;
+    const int4* __restrict__ tri_rec;  // = bvh_rec + tri_off bytes: one allocation, so either kind of record is a 32-bit offset off one base
+    unsigned tri_off;
     int world_root, actor_root;  // reference of each BVH's root
     // emitter next-event estimation (extension): every emitter leaf of the octree as {x, y, z, level << 25 | block pointer},
     // in pre-order — the list of oracle/port.c port_list_emitters

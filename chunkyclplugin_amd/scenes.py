@@ -746,3 +746,27 @@ def cached_outdoor_world(**kw) -> PackedScene:
     except OSError:
         pass
     return sc
+
+
+def cached_entity_world(n_world_tris: int, actor_tris: int = 5000, seed: int = 11, region=((40, 90, 40), (470, 170, 470)), **world_kw) -> PackedScene:
+    """BASELINE configs[4]: cached_outdoor_world(chunks=32, height=256, **world_kw) + add_entities(...) through the same on-disk
+    cache (building the BVH of 10^6 triangles takes about a minute of numpy)."""
+    import hashlib
+    import inspect
+    import os
+    world_kw = dict(dict(chunks=32, height=256), **world_kw)
+    src = inspect.getsource(add_entities) + inspect.getsource(outdoor_world) + inspect.getsource(build_octree) + inspect.getsource(hide_interior)
+    key = hashlib.sha256((repr((n_world_tris, actor_tris, seed, region, sorted(world_kw.items()))) + src).encode()).hexdigest()[:16]
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".scene_cache")
+    path = os.path.join(root, f"entities_{key}.npz")
+    if os.path.exists(path):
+        try:
+            return load_scene(path)
+        except Exception:
+            pass
+    sc = add_entities(cached_outdoor_world(**world_kw), n_world_tris, seed=seed, actor_tris=actor_tris, region=region)
+    try:
+        save_scene(sc, path)
+    except OSError:
+        pass
+    return sc

@@ -8,6 +8,7 @@ rows against the oracle AT THE TIMED PASS COUNT (the instantiation that is timed
   indoor_nee  configs[3]  the same with CHUNKY_OPT_EMITTER_NEE (the configuration's "NEE on": an extension)
   entities    configs[4]  32x32-chunk world + 100 000 world / 5 000 actor triangles, 1920x1080 on one GPU
   entities4k  configs[4]  the same at 3840x2160, rank 0's share of an 8-GPU tile split (what one GPU of the stated config renders)
+  entities1m  configs[4]  1 000 000 world triangles (the upper end of the configuration's 10^5 - 10^6 range), 1920x1080 (on request)
 
     python tools/config_bench.py [names...] > profiles/rNN_config_bench.jsonl"""
 import json
@@ -92,5 +93,8 @@ if __name__ == "__main__":
             res.append(run(sc, "configs[4] at 1920x1080 on one GPU", passes=16, launches=2))
         if "entities4k" in which:
             res.append(run(sc.with_view(3840, 2160), "configs[4] at 3840x2160, rank 0 of 8", passes=16, launches=2, world=8))
+    if "entities1m" in which:   # the upper end of configs[4]'s range: 10^6 world triangles
+        res.append(run(scenes.cached_entity_world(1000000), "configs[4] with 1 000 000 world triangles, 1920x1080 on one GPU", passes=8, launches=2,
+                       check_rows=(250, 630, 1010)))
     for x in res:
         print(json.dumps(x), flush=True)

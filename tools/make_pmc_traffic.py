@@ -35,4 +35,23 @@ out = {
                 "lane_util = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)",
     },
 }
+# what actually limits the kernel (the algorithmic roofline above is a work-rate convention: the scene is cache-resident)
+tcp_cycles = cycles * 256.0              # one L1 (TCP) per CU
+issue = c["SQ_INSTS_VALU"] * 2 / (cycles * 1024)
+lim = {
+    "valu_issue_frac": round(issue, 4),
+    "valu_lane_util": round(d["valu_lane_utilisation"], 4),
+    "valu_lane_frac": round(issue * d["valu_lane_utilisation"], 4),   # useful lane-cycles / all VALU lane-cycles of the launch
+    "wave_wait_frac": round(d["SQ_WAIT_ANY/WAVE_CYCLES"], 3),
+    "l1_tag_lookups_per_cycle": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / tcp_cycles, 3) if "TCP_TOTAL_CACHE_ACCESSES_sum" in c else None,
+    "l1_pending_stall_frac": round(c["TCP_PENDING_STALL_CYCLES_sum"] / tcp_cycles, 3) if "TCP_PENDING_STALL_CYCLES_sum" in c else None,
+    "l2_request_GBps": round(c["TCC_REQ_sum"] * 64 / (cycles / 2.4e9) / 1e9, 1),
+    "l2_request_frac_of_34.5TBps": round(c["TCC_REQ_sum"] * 64 / (cycles / 2.4e9) / 34.5e12, 3),
+    "l2_hit_rate": round(d["l2_hit_rate"], 4),
+    "limiter": "issue + latency: VALU issue slots and the L1's tag look-ups (about one per cycle at most) are both more than half used "
+               "while a third of the wave cycles are waits on dependent reads; HBM is at ~3 % of peak",
+    "note": "l1_tag_lookups_per_cycle = TCP_TOTAL_CACHE_ACCESSES / (cycles x 256 L1s); l2_request_GBps counts TCC_REQ x 64 B against the "
+            "34.5 TB/s aggregate L2 figure of MI355X_MICROARCH.md; cycles = GRBM_GUI_ACTIVE / 8 XCDs at a nominal 2.4 GHz",
+}
+out["limits"] = lim
 print(json.dumps(out, indent=1))
