@@ -1138,6 +1138,7 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
     }
     if (r->pending.size() > 4096)
         if (int rc = collect_timing(r)) return rc;
+    if (r->shard.n_local <= 0) return CHUNKY_OK;  // this rank (or group member) owns no tile of so small an image: nothing to render
     if (r->launch_cap <= 0) r->launch_cap = launch_pass_cap(r, kStagingBytes);
     for (int done = 0; done < n;) {
         PassSeeds ps;

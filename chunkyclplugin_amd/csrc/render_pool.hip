@@ -715,12 +715,6 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
             if (tree != 17) tree = -1;
             park = 16;
             k = tree == 17 ? render_pool<17, 16, true, true> : render_pool<-1, 16, true, true>;
-#if CHUNKY_POOL_BVH_WAVES == 6   // experiment: six waves per SIMD leave LDS for 8 parked paths
-        } else if (true) {
-            park = 8;
-            if (tree != 17) tree = -1;
-            k = tree == 17 ? render_pool<17, 8, false, true> : render_pool<-1, 8, false, true>;
-#endif
         } else if (park == 32) {
             k = tree == 17 ? render_pool<17, 32, false, true> : (tree == 18 ? render_pool<18, 32, false, true> : render_pool<-1, 32, false, true>);
         } else {

@@ -143,3 +143,21 @@ def test_group_errors():
     arr = (C.c_int * 2)(0, 99)
     assert L.chunky_group_create(arr, 2, C.byref(h)) == native.E_NO_DEVICE and not h.value
     assert L.chunky_group_create(arr, 0, C.byref(h)) == native.E_INVALID
+
+
+def test_members_without_a_block_render_nothing(port):
+    """An image of two 16 x 16 blocks on a group of three: the third member owns no block (nothing to render, nothing to
+    gather), the image is still the one-context image; likewise a plain rank without blocks."""
+    sc = gs.make("outdoor").with_view(30, 12)
+    seeds = native.java_random_ints(3)
+    g3 = RendererInstance.group([0, 0, 0])
+    lg, rg = renderer_on(g3, sc)
+    rg.render_passes(seeds)
+    np.testing.assert_array_equal(bits(rg.read()), bits(port.render_passes(sc, seeds)))
+    rg.set_shard(5, 8, 0)   # the group as rank 5 of 8: none of its members owns anything
+    rg.reset()
+    rg.render_passes(seeds)
+    assert not rg.read().any()
+    rg.close()
+    lg.close()
+    g3.close()
