@@ -289,3 +289,18 @@ def test_entity_trace_records(gpu_instance, port, entity_world):
     assert touched >= 5, f"only {touched} of {len(gids)} sampled paths meet an entity: the sample does not exercise the BVH path"
     r.close()
     loader.close()
+
+
+def test_million_triangle_world(gpu_instance, port):
+    """BASELINE configs[4] at the upper end of its range (10^5 - 10^6 triangles): 1 000 000 world + 5 000
+    actor triangles — BVHs of half a million inner nodes, 122 MB of node / triangle records behind 32-bit offsets — whole rows
+    against the oracle.  (The scene comes from .scene_cache when present; building its BVH takes about a minute otherwise.)"""
+    sc = scenes.cached_entity_world(1000000)
+    seeds = native.java_random_ints(2)
+    loader, r = make(gpu_instance, sc)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["bvh"]) == (17, True) and info["pool"] in (16, 32), info
+    compare_rows(r, port, sc, seeds, row_gids(sc, (411, 799)), "10^6 triangles")
+    r.close()
+    loader.close()

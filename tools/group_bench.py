@@ -27,7 +27,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     loader.load_packed(sc)
     r = HipPathTracingRenderer(loader, W, H)
     r.set_camera(sc.projector_type, sc.camera)
-    r.render_passes(seeds[:8])          # warm-up: allocations, first launch
+    r.render_passes(seeds)              # warm-up at the timed launch shape: the staging arrays are allocated here
     r.gather()
     r.reset()
     t0 = time.perf_counter()
