@@ -286,11 +286,9 @@ static void scene_unref(chunky_scene* s) {
 extern "C" int chunky_scene_destroy(chunky_scene* scene) {
     if (scene && !scene->replicas.empty()) {
         const int rc = each_replica(scene, [&](chunky_scene* m_) { return chunky_scene_destroy(m_); });
-        {
-            std::lock_guard<std::recursive_mutex> g(scene->ctx->mu);
-            scene->replicas.clear();
-        }
-        scene_unref(scene);
+        std::lock_guard<std::recursive_mutex> g(scene->ctx->mu);
+        scene->replicas.clear();
+        scene_unref(scene);  // render targets of the group keep the (now empty) shell alive until they are destroyed
         return rc;
     }
     LOCK_SCENE(scene);
@@ -917,6 +915,7 @@ extern "C" int chunky_render_create(chunky_ctx* ctx, chunky_scene* scene, int wi
         return fail(CHUNKY_E_INVALID, "bad image size %dx%d", width, height);
     if (!ctx->members.empty()) {
         std::lock_guard<std::recursive_mutex> g(ctx->mu);
+        if (scene->replicas.size() != ctx->members.size()) return fail(CHUNKY_E_STATE, "chunky_render_create: the scene has been destroyed");
         std::unique_ptr<chunky_render> r(new chunky_render);
         r->ctx = ctx;
         r->scene = scene;
@@ -1514,6 +1513,7 @@ static int device_gamma_table(chunky_ctx* ctx, const float** out) {
 extern "C" int chunky_filter_frame(chunky_ctx* ctx, int width, int height, double exposure, const double* input,
                                    int32_t* argb_out, int type) {
     if (!ctx) return fail(CHUNKY_E_INVALID, "filter_frame: NULL context");
+    if (!ctx->members.empty()) ctx = ctx->members[0];  // a group: the tone map of one frame runs on its first member
     if (width < 0 || height < 0) return fail(CHUNKY_E_INVALID, "filter_frame: %dx%d", width, height);
     const long long n = (long long)width * height;
     if (n == 0) return CHUNKY_OK;
@@ -1535,6 +1535,7 @@ extern "C" int chunky_filter_frame(chunky_ctx* ctx, int width, int height, doubl
 extern "C" int chunky_filter_frame_device(chunky_ctx* ctx, int64_t n_pixels, float exposure, const void* d_input,
                                           void* d_argb, int type, int repeat, float* kernel_ms) {
     if (!ctx) return fail(CHUNKY_E_INVALID, "filter_frame_device: NULL context");
+    if (!ctx->members.empty()) ctx = ctx->members[0];
     if (n_pixels < 0 || repeat < 1) return fail(CHUNKY_E_INVALID, "filter_frame_device: n_pixels=%lld repeat=%d", (long long)n_pixels, repeat);
     if (n_pixels > 0 && (!d_input || !d_argb)) return fail(CHUNKY_E_INVALID, "filter_frame_device: NULL buffer");
     if ((reinterpret_cast<uintptr_t>(d_input) & 7u) || (reinterpret_cast<uintptr_t>(d_argb) & 3u))
@@ -1563,6 +1564,7 @@ extern "C" int chunky_filter_frame_device(chunky_ctx* ctx, int64_t n_pixels, flo
 // ------------------------------------------------------------------------------------ self test
 extern "C" int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const float* a, const float* b, float* out) {
     if (!ctx) return fail(CHUNKY_E_INVALID, "NULL context");
+    if (!ctx->members.empty()) ctx = ctx->members[0];
     if (n < 0 || (n > 0 && (!a || !b || !out))) return fail(CHUNKY_E_INVALID, "selftest_math: bad arguments");
     if (n == 0) return CHUNKY_OK;
     std::lock_guard<std::recursive_mutex> g(ctx->mu);
@@ -1598,6 +1600,7 @@ extern "C" int chunky_selftest_helpers(chunky_scene* scene, int which, int tree,
 
 extern "C" int chunky_selftest_gamma_scan(chunky_ctx* ctx, int curve, uint32_t first_bits, uint64_t count, uint64_t* mismatches, float* worst_estimate) {
     if (!ctx || !mismatches) return fail(CHUNKY_E_INVALID, "selftest_gamma_scan: NULL argument");
+    if (!ctx->members.empty()) ctx = ctx->members[0];
     if (count > (1ull << 32) || (curve != 0 && curve != 2)) return fail(CHUNKY_E_INVALID, "selftest_gamma_scan: curve=%d count=%llu", curve, (unsigned long long)count);
     std::lock_guard<std::recursive_mutex> g(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
