@@ -4,8 +4,8 @@ Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may i
 module; nothing under `chunkyclplugin_amd/` does.
 
 * `ref()`  — oracle/_ref/libchunky_ref.so: the reference OpenCL kernel itself, compiled in place
-             from /root/reference for x86-64 (exists only where it was built; travels as a
-             prebuilt file to the GPU box).
+             from /root/reference for x86-64 (exists only where it was built: the build container;
+             it does not travel to the GPU box).
 * `port()` — oracle/libchunky_port.so: oracle/port.c, the plain-C restatement (buildable
              anywhere with gcc).
 """

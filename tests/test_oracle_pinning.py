@@ -2,8 +2,8 @@
 
 The reference has no tests and no golden vectors, so pinning is by running
 the reference kernel itself: tests/golden/*.npz are outputs of oracle/_ref (rayTracer.cl compiled
-in place for x86-64).  Where oracle/_ref is present (build container, or shipped prebuilt to the
-GPU box) the restatement is also compared against it live on further inputs."""
+in place for x86-64).  Where oracle/_ref is present (the build container) the restatement is also
+compared against it live on further inputs."""
 import os
 
 import numpy as np
