@@ -229,6 +229,43 @@ DEV int pool_slot_gid(const ShardView& T, int width, int height, int slot) {
               y = (by << kTileLog) + (sb / (kTileEdge / kSubW)) * kSubH + px / kSubW;
     return (x < width && y < height) ? y * width + x : width * height;
 }
+// Exact n / d for n < 2^31 by one multiply-high and one shift (d fixed for a launch, the pair made on the host): with 2^s < d <= 2^(s+1)
+// and m = ceil(2^(32+s) / d) — a 32-bit number — the error term m * d - 2^(32+s) is below d, and n * d < 2^(32+s) keeps the quotient exact.
+struct FastDiv {
+    unsigned m;  // 0: d == 1
+    int s;
+};
+inline FastDiv fast_div(unsigned d) {
+    if (d <= 1) return FastDiv{0u, 0};
+    int s = 0;
+    while ((2u << s) < d) s++;  // 2^s < d <= 2^(s+1)
+    const unsigned long long m = (((unsigned long long)1 << (32 + s)) + d - 1) / d;
+    return FastDiv{(unsigned)m, s};
+}
+DEV unsigned fast_quotient(unsigned n, FastDiv f) { return f.m ? __umulhi(n, f.m) >> f.s : n; }
+
+// pool_slot_gid with the pixel's column and row, and the division by the tile row length as a multiply (render_pool's new samples)
+struct SlotPixel {
+    int gid, x, y;
+};
+DEV SlotPixel pool_slot_pixel(const ShardView& T, int width, int height, int slot, FastDiv by_bw) {
+    if (T.world != 1 && T.tile != 0) {
+        const int gid = slot < T.n_local ? shard_gid(T, slot) : width * height;
+        return SlotPixel{gid, gid % width, gid / width};
+    }
+    const int bw = (width + kTileEdge - 1) >> kTileLog;
+    int b = slot >> (2 * kTileLog);
+    const int i = slot & (kSampleTile - 1);
+    if (T.world != 1) {
+        b = b * T.world + T.rank;
+        if (b >= bw * ((height + kTileEdge - 1) >> kTileLog)) return SlotPixel{width * height, 0, 0};
+    }
+    const int by = (int)fast_quotient((unsigned)b, by_bw), bx = b - by * bw;
+    const int sb = i / kSubBlock, px = i % kSubBlock;
+    const int x = (bx << kTileLog) + (sb % (kTileEdge / kSubW)) * kSubW + px % kSubW,
+              y = (by << kTileLog) + (sb / (kTileEdge / kSubW)) * kSubH + px / kSubW;
+    return SlotPixel{(x < width && y < height) ? y * width + x : width * height, x, y};
+}
 __host__ __device__ inline long long pool_tiles(const ShardView& T, int width, int height) {
     if (T.world != 1) return ((long long)T.n_local + kSampleTile - 1) / kSampleTile;  // runs of T.tile pixels, or (T.tile == 0) the rank's blocks
     return (long long)((width + kTileEdge - 1) >> kTileLog) * ((height + kTileEdge - 1) >> kTileLog);
@@ -433,6 +470,8 @@ struct WaveArgs {
     float* staging;        // render_pool: radiance of every sample of the launch, [tile][pass][slot in tile][3]
     unsigned n_samples;    // render_pool: tiles of kSampleTile pixel slots (the last one padded) x P.n
     unsigned xcd_stripe;   // render_pool: samples per range (xcd_claim): the tiles over kXcdRanges, rounded up, x P.n x kSampleTile
+    FastDiv div_sub;       // render_pool: division of a sample index by P.n x kSubBlock (the samples of one sub-block)
+    FastDiv div_bw;        // render_pool: division of a tile index by the tiles per image row
 };
 static_assert(sizeof(WaveArgs) <= 4096, "launch arguments must fit the 4 KB kernel-argument segment");
 typedef const WaveArgs __attribute__((address_space(4))) * WaveArgPtr;

@@ -574,14 +574,15 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                     const ShardView T = arg_copy(&A->T);
                     // sidx = ((tile * sub-blocks per tile + sub-block) * passes + pass) * kSubBlock + slot in the sub-block
                     const unsigned per_sub = (unsigned)A->P.n * (unsigned)kSubBlock;
-                    const unsigned sub = sidx / per_sub, rem = sidx - sub * per_sub;  // sub = tile * (kSampleTile / kSubBlock) + sub-block
+                    const unsigned sub = fast_quotient(sidx, arg_copy(&A->div_sub)), rem = sidx - sub * per_sub;  // sub = tile * (kSampleTile / kSubBlock) + sub-block
                     const unsigned pass = rem / (unsigned)kSubBlock;
                     const int slot = (int)(sub * (unsigned)kSubBlock + (rem & (unsigned)(kSubBlock - 1)));
-                    const int gid = pool_slot_gid(T, C.width, C.height, slot);
+                    const SlotPixel px = pool_slot_pixel(T, C.width, C.height, slot, arg_copy(&A->div_bw));
+                    const int gid = px.gid;
                     if (gid < C.width * C.height) {  // else: a padding slot, nothing to render (the lane claims again)
                         unsigned rng = (unsigned)A->P.seed[pass] + (unsigned)gid;
                         rt_pcg_next(&rng);
-                        const RayOD pr = primary_ray(C, gid, rng, false);
+                        const RayOD pr = primary_ray(C, gid, rng, false, px.x, px.y);
                         L.sidx = (int)sidx;
                         L.rng = rng;
                         L.o = pr.o;
@@ -755,7 +756,8 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     e = hipMemsetAsync(work_counter + kXcdCounters, 0, kXcdRanges * sizeof(int), stream);  // the per-XCD sample ranges (xcd_claim)
     if (e != hipSuccess) return e;
     WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)depth, staging, (unsigned)n_samples,
-               (unsigned)((n_tiles + kXcdRanges - 1) / kXcdRanges * kSampleTile * P.n)};
+               (unsigned)((n_tiles + kXcdRanges - 1) / kXcdRanges * kSampleTile * P.n), fast_div((unsigned)P.n * (unsigned)kSubBlock),
+               fast_div((unsigned)((C.width + kTileEdge - 1) >> kTileLog))};
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

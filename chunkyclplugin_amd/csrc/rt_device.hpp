@@ -658,11 +658,12 @@ struct RayOD {
 };
 // Returned by value through scalars (ox..dz each assigned once per branch): out-parameters written
 // in both branches end up as a select between two addresses, which keeps them in scratch memory.
-DEV RayOD primary_ray(const CameraView& C, int gid, unsigned& rng, bool unit_dir) {
+// (px, py) = (gid % width, gid / width): callers that know the pixel's column and row pass them and save the two divisions
+DEV RayOD primary_ray(const CameraView& C, int gid, unsigned& rng, bool unit_dir, int px, int py) {
     float ox, oy, oz, dx, dy, dz;
     if (C.projector_type != -1) {
-        float x = -C.half_width + ((float)(gid % C.width) + rt_pcg_float(&rng)) * C.inv_height;
-        float y = (float)(-0.5 + (double)(((float)(gid / C.width) + rt_pcg_float(&rng)) * C.inv_height));
+        float x = -C.half_width + ((float)px + rt_pcg_float(&rng)) * C.inv_height;
+        float y = (float)(-0.5 + (double)(((float)py + rt_pcg_float(&rng)) * C.inv_height));
         f3 lo = mk3(0, 0, 0);
         f3 ld = mk3(C.fov_tan * x, C.fov_tan * y, 1.0f);
         if (C.aperture > 0) {
@@ -693,6 +694,9 @@ DEV RayOD primary_ray(const CameraView& C, int gid, unsigned& rng, bool unit_dir
         dz = r[5];
     }
     return RayOD{mk3(ox, oy, oz), mk3(dx, dy, dz)};
+}
+DEV RayOD primary_ray(const CameraView& C, int gid, unsigned& rng, bool unit_dir) {
+    return primary_ray(C, gid, rng, unit_dir, gid % C.width, gid / C.width);
 }
 
 }  // namespace chunky
