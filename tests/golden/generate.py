@@ -12,6 +12,7 @@ kernel (tonemap/include/post_processing_filter.cl, compiled in place the same wa
 exposures, and the ARGB words for every filter type, plus pow known answers.
 timed_rows.npz (`... generate.py timed`): rows of the five BASELINE views at their timed sizes (write_timed).
 helpers.npz (`... generate.py helpers`): known answers of the reference's exported helper functions (write_helpers).
+libm_platform.npz (`... generate.py libm`): images of the reference object on a second platform layer (glibc libm): write_libm.
 """
 import os
 import sys
@@ -86,6 +87,28 @@ def write_helpers(ref):
     np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
 
 
+LIBM_SCENES = ("outdoor", "indoor_sun", "entities")
+LIBM_SPP = 32
+
+
+def write_libm():
+    """libm_platform.npz: the SAME reference object linked against a SECOND conforming platform layer — glibc libm and unfused
+    dot / cross / normalize instead of rt_math.h (`make -C oracle ref_libm`) — renders three golden scenes at LIBM_SPP passes.
+    Two conforming platforms differ in last bits, so these images are compared statistically (tests/test_platform_layer.py):
+    a guard that does not share rt_math.h with what it checks."""
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(os.path.dirname(HERE), "..", "oracle"), "ref_libm"], check=True, stdout=subprocess.DEVNULL)
+    libm = binding.RefLib(os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libchunky_ref_libm.so"))
+    seeds = scenes.java_random_ints(LIBM_SPP)
+    out = {"seeds": seeds}
+    for name in LIBM_SCENES:
+        sc = gs.make(name)
+        out[name + "_digest"] = gs.input_digest(sc)
+        out[name + "_res"] = libm.render_passes(binding.SceneHandle(sc), seeds)
+        print("libm", name, float(out[name + "_res"].mean()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "libm_platform.npz"), **out)
+
+
 def main():
     ref = binding.ref()
     assert ref is not None, "needs /root/reference"
@@ -95,6 +118,8 @@ def main():
         return write_timed(ref)
     if "helpers" in sys.argv[1:]:
         return write_helpers(ref)
+    if "libm" in sys.argv[1:]:
+        return write_libm()
     seeds = scenes.java_random_ints(gs.N_PASSES)
     for name in gs.NAMES:
         sc = gs.make(name)
@@ -129,6 +154,7 @@ def main():
     write_filter(ref)
     write_timed(ref)
     write_helpers(ref)
+    write_libm()
 
 
 if __name__ == "__main__":
