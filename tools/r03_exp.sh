@@ -4,7 +4,7 @@
 for v in $1; do
   if [ "$v" = default ]; then unset CHUNKY_HIP_LIB; else export CHUNKY_HIP_LIB=$PWD/.variants/libchunky_hip_$v.so; fi
   for rep in 1 2; do
-    timeout 200 python bench.py --no-cpu --steps 8 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('bench $v', d['value'], 'launch_ms', d['roofline']['launch_ms'])"
+    timeout 90 python bench.py --no-cpu --steps 8 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('bench $v', d['value'], 'launch_ms', d['roofline']['launch_ms'])"
   done
 done
 for v in $2; do
