@@ -54,9 +54,17 @@ def build(force: bool = False, extra_flags=(), out: Optional[str] = None, objdir
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     if force or _needs_build():
         # one hipcc per translation unit, side by side (objects under csrc/build/, git-ignored), then one link
+        import fcntl
         from concurrent.futures import ThreadPoolExecutor
         objdir = objdir or os.path.join(CSRC, "build")
         os.makedirs(objdir, exist_ok=True)
+        # several ranks of one job may arrive here at once (bench.py --gpus N on a box without the library): one builds,
+        # the others wait for it and find the library there
+        lock = open(os.path.join(objdir, ".lock"), "w")
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _needs_build():
+            lock.close()
+            return out or LIB_PATH
         flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
 
         def compile_one(src):
@@ -70,6 +78,7 @@ def build(force: bool = False, extra_flags=(), out: Optional[str] = None, objdir
         with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
             objs = list(pool.map(compile_one, SOURCES))
         proc = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out or LIB_PATH], capture_output=True, text=True)
+        lock.close()  # (also released when an exception unwinds past here: the file object goes away)
         if proc.returncode != 0:
             raise RuntimeError("hipcc link failed:\n" + proc.stderr[-4000:])
     return out or LIB_PATH
