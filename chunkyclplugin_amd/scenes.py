@@ -714,6 +714,26 @@ def save_scene(sc: PackedScene, path: str, compressed: bool = False) -> None:
     os.replace(tmp, path)
 
 
+def save_raw(sc: PackedScene, path: str) -> None:
+    """The scene as a flat dump a host without numpy reads (examples/host_example.cpp): "CHKSCN01", then per array a record
+    {name[16], int32 dtype (0 int32, 1 uint8, 2 float32), int32 ndim, int64 dims[4], payload}, little-endian."""
+    import struct
+    arrays = [("meta", np.array([sc.octree_depth, sc.projector_type, sc.width, sc.height], np.int32)),
+              ("sky_intensity", np.array([sc.sky_intensity], np.float32))]
+    for f in _ARRAY_FIELDS:
+        a = getattr(sc, f)
+        dt = np.uint8 if f in ("atlas", "sky") else (np.float32 if f == "camera" else np.int32)
+        arrays.append((f, np.ascontiguousarray(a, dt)))
+    with open(path, "wb") as out:
+        out.write(b"CHKSCN01")
+        for name, a in arrays:
+            code = {np.dtype(np.int32): 0, np.dtype(np.uint8): 1, np.dtype(np.float32): 2}[a.dtype]
+            dims = list(a.shape) + [1] * (4 - a.ndim)
+            out.write(name.encode().ljust(16, b"\0"))
+            out.write(struct.pack("<ii4q", code, a.ndim, *dims))
+            out.write(a.tobytes())
+
+
 def load_scene(path: str) -> PackedScene:
     z = np.load(path)
     depth, proj, w, h = (int(v) for v in z["meta"])

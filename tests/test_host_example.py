@@ -1,0 +1,84 @@
+"""examples/host_example.cpp — a C++ host that binds nothing but include/chunky_hip.h: it compiles with g++ against the header,
+links the library, fails loudly where there is no GPU, and on the GPU runs the reference's pass loop
+(OpenClPathTracingRenderer.java:95-184) to the same doubles as the oracle driven through the same merges."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_scenes as gs
+from chunkyclplugin_amd import native, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host_example(tmp_path_factory):
+    native.build()
+    exe = str(tmp_path_factory.mktemp("host") / "host_example")
+    cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host_example.cpp"),
+           "-o", exe, "-L" + native.PKG_DIR, "-lchunky_hip", "-Wl,-rpath," + native.PKG_DIR, "-Wl,--allow-shlib-undefined"]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    return exe
+
+
+def run(exe, sc, tmp_path, spp, interval, devices=()):
+    raw, out = str(tmp_path / "scene.raw"), str(tmp_path / "out.f64")
+    scenes.save_raw(sc, raw)
+    proc = subprocess.run([exe, raw, out, str(spp), str(interval), *[str(d) for d in devices]], capture_output=True, text=True, timeout=300)
+    return proc, out
+
+
+def test_host_example_builds_and_fails_loudly_without_a_gpu(host_example, tmp_path):
+    sc = scenes.tiny_scene(width=48, height=32)
+    proc, out = run(host_example, sc, tmp_path, 4, 2)
+    if native.lib().chunky_device_count() > 0:
+        assert proc.returncode == 0, proc.stderr
+    else:  # no CPU fallback: the first call that needs the device says so and nothing is written
+        assert proc.returncode == 2 and "no HIP device" in proc.stderr and not os.path.exists(out), (proc.returncode, proc.stderr)
+    # a file that is not a scene dump
+    bad = tmp_path / "bad.raw"
+    bad.write_bytes(b"not a scene")
+    proc = subprocess.run([host_example, str(bad), str(tmp_path / "x.f64"), "1"], capture_output=True, text=True)
+    assert proc.returncode == 1 and "cannot read" in proc.stderr
+
+
+def oracle_loop(port, sc, target, interval):
+    seeds = scenes.java_random_ints(target)
+    want = np.zeros(sc.width * sc.height * 3, np.float64)
+    done = 0
+    while done < target:
+        m = min(interval, target - done)
+        pass_buf = port.render_passes(sc, seeds[done:done + m]).astype(np.float64)
+        want = (want * done + pass_buf * m) * (1.0 / (done + m))
+        done += m
+    return want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["indoor", "entities"])
+def test_host_example_runs_the_reference_pass_loop(host_example, tmp_path, port, name):
+    sc = gs.make(name).with_view(64, 48)
+    target, interval = 10, 4
+    proc, out = run(host_example, sc, tmp_path, target, interval)
+    assert proc.returncode == 0, proc.stderr
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["spp"] == target and line["members"] == 1 and line["size"] == [64, 48]
+    got = np.fromfile(out, np.float64)
+    np.testing.assert_array_equal(got.view(np.uint64), oracle_loop(port, sc, target, interval).view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_host_example_on_a_group(host_example, tmp_path, port):
+    """three members behind one context (all on device 0 here): the same image, gathered per merge"""
+    sc = gs.make("indoor").with_view(80, 48)
+    target, interval = 6, 4
+    proc, out = run(host_example, sc, tmp_path, target, interval, devices=(0, 0, 0))
+    assert proc.returncode == 0, proc.stderr
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["members"] == 3
+    got = np.fromfile(out, np.float64)
+    np.testing.assert_array_equal(got.view(np.uint64), oracle_loop(port, sc, target, interval).view(np.uint64))
