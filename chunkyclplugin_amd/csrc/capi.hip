@@ -1373,7 +1373,7 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
     int samp_spp = *scene_spp;         // sceneSpp[0], :92
     auto last_callback = std::chrono::steady_clock::now();
     if (int rc = chunky_render_reset(r)) return rc;  // new float[] passBuffer uploaded with the buffer, :61,71
-    int launch_passes = 1;             // grows until a launch takes ~50 ms, so postRender is polled often enough
+    int launch_passes = 1;             // adapts to ~80 ms per launch (below), so postRender is polled often enough
     while (logical_spp < target_spp) { // :102
         int buffer_spp = 0;            // bufferSppReal
         int until_merge = target_spp - logical_spp < merge_interval ? target_spp - logical_spp : merge_interval;
@@ -1399,8 +1399,17 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
             if (cb.progress) cb.progress(cb.user, *scene_spp);
             if (cb.regenerate_camera) cb.regenerate_camera(cb.user);         // :146-148
             double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-            if (ms < 25.0 && launch_passes < kMaxPassesPerLaunch) launch_passes *= 2;
-            if (ms > 90.0 && launch_passes > 1) launch_passes /= 2;
+            // passes per launch: as many as fit ~80 ms at the rate just measured (postRender is polled between launches, at least
+            // every 100 ms where a launch allows it), at most eight times the last launch — a launch of few passes overstates
+            // the time per pass (its fixed costs), so the sequence climbs 1, 8, 64, ... and settles; it comes down the same way
+            {
+                const double per_pass = ms / (double)m;
+                int want = per_pass > 0.0 ? (int)(80.0 / per_pass) : kMaxPassesPerLaunch;
+                if (want > launch_passes * 8) want = launch_passes * 8;
+                if (want > kMaxPassesPerLaunch) want = kMaxPassesPerLaunch;
+                if (want < 1) want = 1;
+                if (want > launch_passes || ms > 90.0) launch_passes = want;
+            }
             if (!save && cb.post_render && std::chrono::duration<double, std::milli>(t1 - last_callback).count() > 100.0 &&
                 (!cb.poll_gate || cb.poll_gate(cb.user))) {  // :153-157; the gate is `!manager.shouldFinalize()` (:154)
                 last_callback = t1;
