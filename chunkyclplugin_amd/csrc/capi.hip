@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/chunky_hip.h"
@@ -1424,8 +1425,20 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
         if (int rc = chunky_render_read(r, pass_buffer.data(), n)) return rc;  // :164-166
         const double sinv = 1.0 / (samp_spp + buffer_spp);                   // :169
         const double a = samp_spp, b = buffer_spp;
-        for (int64_t i = 0; i < n; i++)                                       // :173
-            sample_buffer[i] = (sample_buffer[i] * a + (double)pass_buffer[(size_t)i] * b) * sinv;
+        {   // :172-177: the reference merges on Chunky's common worker threads; here a few host threads, each its own range
+            auto merge = [&](int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; i++)                             // :173
+                    sample_buffer[i] = (sample_buffer[i] * a + (double)pass_buffer[(size_t)i] * b) * sinv;
+            };
+            unsigned workers = std::thread::hardware_concurrency();
+            workers = workers > 16 ? 16 : (workers < 1 ? 1 : workers);
+            if (n < (int64_t)1 << 18) workers = 1;
+            std::vector<std::thread> pool;
+            const int64_t chunk = (n + workers - 1) / workers;
+            for (unsigned w = 1; w < workers; w++) pool.emplace_back(merge, (int64_t)w * chunk < n ? (int64_t)w * chunk : n, (int64_t)(w + 1) * chunk < n ? (int64_t)(w + 1) * chunk : n);
+            merge(0, chunk < n ? chunk : n);
+            for (auto& t : pool) t.join();
+        }
         samp_spp += buffer_spp;
         logical_spp += buffer_spp;                                            // :178
         if (cb.merged) cb.merged(cb.user, samp_spp);                          // :174-176
