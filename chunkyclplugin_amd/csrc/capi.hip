@@ -168,7 +168,8 @@ extern "C" int chunky_device_name(int device, char* buf, int buf_len) {
     hipDeviceProp_t prop;
     if (device < 0 || device >= chunky_device_count()) return fail(CHUNKY_E_NO_DEVICE, "no HIP device %d", device);
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    // (some boxes report an empty marketing name)
+    snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName, prop.multiProcessorCount);
     return CHUNKY_OK;
 }
 
