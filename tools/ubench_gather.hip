@@ -145,6 +145,48 @@ static double run_coop(const int4* table, unsigned records, int steps, int* out,
     return (double)blocks * 256 * steps / (ms * 1e-3);
 }
 
+// one lane per record with LOADS loads of WIDTH dwords each (the rest of the record is not read): what a lane-read costs by width
+template <int LOADS, int WIDTH>
+__global__ __launch_bounds__(256) void chase_width(const int* __restrict__ table, unsigned mask, int steps, int* out) {
+    const unsigned lane = threadIdx.x + blockIdx.x * blockDim.x;
+    unsigned idx = (lane * 2654435761u) & mask;
+    int acc = 0;
+    for (int s = 0; s < steps; ++s) {
+        const int* p = table + (size_t)idx * 16;
+        int x = 0;
+#pragma unroll
+        for (int l = 0; l < LOADS; l++) {
+            if (WIDTH == 4) {
+                const int4 v = *(const int4*)(p + 4 * l);
+                x ^= v.x;
+                acc += v.y + v.z + v.w;
+            } else if (WIDTH == 2) {
+                const int2 v = *(const int2*)(p + 4 * l);
+                x ^= v.x;
+                acc += v.y;
+            } else {
+                x ^= p[4 * l];
+            }
+        }
+        idx = ((unsigned)x + lane * 0x9E3779B1u + (unsigned)s * 40503u) & mask;
+    }
+    out[lane] = acc + idx;
+}
+template <int LOADS, int WIDTH>
+static double run_width(const int4* table, unsigned records, int steps, int* out, int blocks) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((chase_width<LOADS, WIDTH>), dim3(blocks), dim3(256), 0, 0, (const int*)table, records - 1, steps / 10, out);
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((chase_width<LOADS, WIDTH>), dim3(blocks), dim3(256), 0, 0, (const int*)table, records - 1, steps, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return (double)blocks * 256 * steps / (ms * 1e-3);
+}
+
 template <int SHARE>
 static double run(const int4* table, unsigned records, int steps, int* out, int blocks) {
     hipEvent_t a, b;
@@ -194,6 +236,14 @@ int main() {
                h.size() * 4, g / 1e9, w / 1e9, t / 1e9, g / l, w / l, t / l, same ? "true" : "false");
         printf("{\"table_bytes\": %zu, \"lane_Grec_s\": %.2f, \"pair_Grec_s\": %.2f, \"quad_Grec_s\": %.2f, \"pair_vs_lane\": %.3f, \"quad_vs_lane\": %.3f}\n",
                h.size() * 4, l / 1e9, p / 1e9, q / 1e9, p / l, q / l);
+        printf("{\"table_bytes\": %zu, \"lane_Grec_s_by_loads_x_dwords\": {\"4x4\": %.2f, \"3x4\": %.2f, \"2x4\": %.2f, \"1x4\": %.2f, \"4x2\": %.2f, \"4x1\": %.2f}}\n", h.size() * 4,
+               run_width<4, 4>(table, records, steps, out, blocks) / 1e9, run_width<3, 4>(table, records, steps, out, blocks) / 1e9,
+               run_width<2, 4>(table, records, steps, out, blocks) / 1e9, run_width<1, 4>(table, records, steps, out, blocks) / 1e9,
+               run_width<4, 2>(table, records, steps, out, blocks) / 1e9, run_width<4, 1>(table, records, steps, out, blocks) / 1e9);
+        printf("{\"table_bytes\": %zu, \"one_load_per_record_Grec_s_by_dwords\": {\"1x1\": %.2f, \"1x2\": %.2f, \"1x4\": %.2f, \"2x1\": %.2f, \"2x2\": %.2f}}\n", h.size() * 4,
+               run_width<1, 1>(table, records, steps, out, blocks) / 1e9, run_width<1, 2>(table, records, steps, out, blocks) / 1e9,
+               run_width<1, 4>(table, records, steps, out, blocks) / 1e9, run_width<2, 1>(table, records, steps, out, blocks) / 1e9,
+               run_width<2, 2>(table, records, steps, out, blocks) / 1e9);
         CK(hipFree(table));
     }
     return 0;
