@@ -563,19 +563,16 @@ static bool build_quad_aux(const std::vector<int32_t>& B, const std::vector<int3
 //               (unit normal, its dot with the origin, |xv|^2, |yv|^2) evaluated here with the kernel's own rt_math.h
 // A block whose model cannot be re-laid out (pointer outside its palette, more than 255 primitives, a material pointer
 // that is not a whole material) keeps model record 0 and takes the path that reads the packed palettes as they are.
-static int rebuild_derived(chunky_scene* s) {
-    const std::vector<int32_t>&B = s->host_blocks, &M = s->host_materials, &A = s->host_aabbs, &Q = s->host_quads;
-    hipStream_t st = s->ctx->stream;
-    HIP_TRY(hipStreamSynchronize(st));  // queued passes may still read the old copies
-    s->block_info.release();
-    s->quad_aux.release();
-    s->mat8.release();
-    s->aabb_rec.release();
-    s->quad_rec.release();
-    s->derived_dirty = false;
-    if (B.empty() || M.empty()) return CHUNKY_OK;
+// The host half of rebuild_derived: everything it derives from the four palettes, as plain vectors (no device call: this is the part
+// that reads caller-supplied ints, and tests/sanitize/capi_host_fuzz.cpp runs it under AddressSanitizer on hostile palettes).
+struct DerivedRecords {
+    std::vector<int32_t> info, mat8, aabb_rec, quad_rec;
+};
+static void derive_records(const std::vector<int32_t>& B, const std::vector<int32_t>& M, const std::vector<int32_t>& A, const std::vector<int32_t>& Q,
+                           DerivedRecords* out) {
     const size_t n_blocks = B.size() / 2, n_mats = M.size() / 6;
-    std::vector<int32_t> mat8(n_mats * 8, 0);
+    std::vector<int32_t>&mat8 = out->mat8, &info = out->info, &aabb_rec = out->aabb_rec, &quad_rec = out->quad_rec;
+    mat8.assign(n_mats * 8, 0);
     for (size_t m = 0; m < n_mats; m++)
         for (int w = 0; w < 6; w++) mat8[m * 8 + w] = M[m * 6 + w];  // word 5 (spec | metal | rough) rides in the second word
     auto mat_index = [&](int32_t ptr, int32_t* out) {  // packed material pointer -> index of its first 16-byte word in mat8
@@ -583,7 +580,9 @@ static int rebuild_derived(chunky_scene* s) {
         *out = (ptr / 6) * 2;
         return true;
     };
-    std::vector<int32_t> info(n_blocks * 8, 0), aabb_rec, quad_rec;
+    info.assign(n_blocks * 8, 0);
+    aabb_rec.clear();
+    quad_rec.clear();
     std::vector<int64_t> aabb_at(A.size(), -1), quad_at(Q.size(), -1);  // model pointer -> first record (models are shared between blocks)
     for (size_t k = 0; k < n_blocks; k++) {
         int32_t* e = &info[k * 8];
@@ -597,9 +596,30 @@ static int rebuild_derived(chunky_scene* s) {
             } else {
                 e[0] = 0x7FFFFFFF;  // malformed cube: an unknown model type never hits (K/block.h:44-47)
             }
-        } else if (type == 2 && ptr >= 0 && (size_t)ptr < A.size()) {
+        } else if (type == 2 || type == 3) {
+            // A model whose pointer, primitive count or material pointers leave their palettes would make the kernels read outside
+            // device memory (the reference has no such check: its behaviour there is undefined).  Such a block never hits, like
+            // an unknown model type (K/block.h:44-47); every well-formed block is untouched by this.
+            const std::vector<int32_t>& P = type == 2 ? A : Q;
+            const int64_t stride = type == 2 ? 13 : 15;
+            bool sound = ptr >= 0 && (size_t)ptr < P.size();
+            if (sound) {
+                const int64_t count = P[(size_t)ptr];
+                sound = count >= 0 && (size_t)(ptr + 1 + stride * count) <= P.size();
+                for (int64_t i = 0; sound && i < count; i++) {
+                    const int32_t* prim = &P[(size_t)(ptr + 1 + stride * i)];
+                    if (type == 2) {
+                        for (int w = 1; w < 6 && sound; w++) sound = prim[7 + w] >= 0 && (size_t)prim[7 + w] + 6 <= M.size();  // E, S, W, T, B: the ones that are read
+                    } else {
+                        sound = prim[13] >= 0 && (size_t)prim[13] + 6 <= M.size();
+                    }
+                }
+            }
+            if (!sound) e[0] = 0x7FFFFFFF;
+        }
+        if (e[0] == 2) {
             const int64_t count = A[(size_t)ptr];
-            if (count < 1 || count > 255 || (size_t)(ptr + 1 + 13 * count) > A.size()) continue;
+            if (count < 1 || count > 255) continue;
             if (aabb_at[(size_t)ptr] < 0) {
                 const int64_t first = (int64_t)aabb_rec.size() / 12;
                 bool ok = true;
@@ -618,9 +638,9 @@ static int rebuild_derived(chunky_scene* s) {
                 }
             }
             if (aabb_at[(size_t)ptr] >= 0 && aabb_at[(size_t)ptr] < (1 << 22)) e[7] = (int32_t)((aabb_at[(size_t)ptr] << 8) | count);
-        } else if (type == 3 && ptr >= 0 && (size_t)ptr < Q.size()) {
+        } else if (e[0] == 3) {
             const int64_t count = Q[(size_t)ptr];
-            if (count < 1 || count > 255 || (size_t)(ptr + 1 + 15 * count) > Q.size()) continue;
+            if (count < 1 || count > 255) continue;
             if (quad_at[(size_t)ptr] < 0) {
                 const int64_t first = (int64_t)quad_rec.size() / 24;
                 bool ok = true;
@@ -662,10 +682,25 @@ static int rebuild_derived(chunky_scene* s) {
             if (quad_at[(size_t)ptr] >= 0 && quad_at[(size_t)ptr] < (1 << 22)) e[7] = (int32_t)((quad_at[(size_t)ptr] << 8) | count);
         }
     }
-    HIP_TRY(s->block_info.upload(info.data(), info.size() * 4, st));
-    HIP_TRY(s->mat8.upload(mat8.data(), mat8.size() * 4, st));
-    if (!aabb_rec.empty()) HIP_TRY(s->aabb_rec.upload(aabb_rec.data(), aabb_rec.size() * 4, st));
-    if (!quad_rec.empty()) HIP_TRY(s->quad_rec.upload(quad_rec.data(), quad_rec.size() * 4, st));
+}
+
+static int rebuild_derived(chunky_scene* s) {
+    const std::vector<int32_t>&B = s->host_blocks, &M = s->host_materials, &A = s->host_aabbs, &Q = s->host_quads;
+    hipStream_t st = s->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(st));  // queued passes may still read the old copies
+    s->block_info.release();
+    s->quad_aux.release();
+    s->mat8.release();
+    s->aabb_rec.release();
+    s->quad_rec.release();
+    s->derived_dirty = false;
+    if (B.empty() || M.empty()) return CHUNKY_OK;
+    DerivedRecords d;
+    derive_records(B, M, A, Q, &d);
+    HIP_TRY(s->block_info.upload(d.info.data(), d.info.size() * 4, st));
+    HIP_TRY(s->mat8.upload(d.mat8.data(), d.mat8.size() * 4, st));
+    if (!d.aabb_rec.empty()) HIP_TRY(s->aabb_rec.upload(d.aabb_rec.data(), d.aabb_rec.size() * 4, st));
+    if (!d.quad_rec.empty()) HIP_TRY(s->quad_rec.upload(d.quad_rec.data(), d.quad_rec.size() * 4, st));
     std::vector<float> aux;  // for quads that kept the packed path
     if (build_quad_aux(B, Q, &aux)) HIP_TRY(s->quad_aux.upload(aux.data(), aux.size() * 4, st));
     return CHUNKY_OK;
@@ -749,6 +784,35 @@ static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_r
     tri_rec->clear();
     if (!build(s->host_world_bvh, s->world_empty, world_root)) return false;
     if (!build(s->host_actor_bvh, s->actor_empty, actor_root)) return false;
+    return true;
+}
+
+// Every leaf of an entity BVH has to lie inside the triangle palette, every triangle's material inside the material palette: the
+// kernels follow these ints as they are (the reference does too — with hostile data its reads are undefined; here the render call
+// is refused instead).  Node links were checked by chunky_scene_set_bvh.
+static bool bvh_leaves_sound(const std::vector<int32_t>& N, bool empty, const std::vector<int32_t>& T, const std::vector<int32_t>& M) {
+    if (empty || N.size() < 7) return true;
+    std::vector<int64_t> todo{0};  // the nodes the walk can reach (first child at +7, second at node[0]: K/bvh.h:72-85)
+    size_t visited = 0;
+    while (!todo.empty()) {
+        const int64_t at = todo.back();
+        todo.pop_back();
+        if (at < 0 || (size_t)at + 7 > N.size() || ++visited > N.size()) return false;
+        const int32_t head = N[(size_t)at];
+        if (head > 0) {
+            todo.push_back(at + 7);
+            todo.push_back((int64_t)head);
+            continue;
+        }
+        const int64_t prim = -(int64_t)head;
+        if ((size_t)prim >= T.size()) return false;
+        const int64_t count = T[(size_t)prim];
+        if (count < 0 || (size_t)(prim + 1 + 20 * count) > T.size()) return false;
+        for (int64_t i = 0; i < count; i++) {
+            const int32_t mp = T[(size_t)(prim + 20 + 20 * i)];  // word 19 of the triangle
+            if (mp < 0 || (size_t)mp + 6 > M.size()) return false;
+        }
+    }
     return true;
 }
 
@@ -848,6 +912,9 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
         HIP_TRY(hipStreamSynchronize(s->ctx->stream));
         s->bvh_rec.release();
         s->tri_off = 0;
+        if (!bvh_leaves_sound(s->host_world_bvh, s->world_empty, s->host_trigs, s->host_materials) ||
+            !bvh_leaves_sound(s->host_actor_bvh, s->actor_empty, s->host_trigs, s->host_materials))
+            return fail(CHUNKY_E_INVALID, "an entity BVH leaf or a triangle's material lies outside its palette");
         std::vector<int32_t> nodes, tris;
         if ((!s->world_empty || !s->actor_empty) && build_bvh_records(s, &nodes, &tris, &s->world_root, &s->actor_root)) {
             if (nodes.empty()) nodes.resize(16, 0);  // both roots are leaves
@@ -864,6 +931,7 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
         if (int rc = refresh_emitters(s)) return rc;
     v->emitters = want_emitters ? (const int4*)s->emitters.p : nullptr;
     v->n_emitters = want_emitters ? (int)(s->host_emitters.size() / 4) : 0;
+    v->n_block_ints = (int)(s->host_blocks.size() < 0x7FFFFFFFu ? s->host_blocks.size() : 0x7FFFFFFFu);
     v->bvh_rec = (const int4*)s->bvh_rec.p;
     v->tri_rec = s->bvh_rec.p ? (const int4*)((const char*)s->bvh_rec.p + s->tri_off) : nullptr;
     v->tri_off = (unsigned)s->tri_off;

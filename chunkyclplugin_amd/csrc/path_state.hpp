@@ -37,7 +37,8 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
             data = tree[data + ((((bx >> level) & 1) << 2) | (((by >> level) & 1) << 1) | ((bz >> level) & 1))];
         }
         data = -data;
-        kind = (data == 0 || data == kAnyType) ? 2 : 1;
+        // (a block pointer beyond the palette — hostile data; the reference's read there is undefined — never intersects)
+        kind = (data == 0 || data == kAnyType || (unsigned)data + 1u >= (unsigned)S.n_block_ints) ? 2 : 1;
     } else {
         const uint32_t* __restrict__ tree = S.wide;
         int e = 0;

@@ -16,6 +16,7 @@
 //
 // With bits = {3,3,3} a depth-9 world needs at most 3 dependent loads per lookup instead of 9.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
