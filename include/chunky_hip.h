@@ -68,6 +68,14 @@ const char* chunky_version(void);
 int chunky_scene_create(chunky_ctx* ctx, chunky_scene** out);
 int chunky_scene_destroy(chunky_scene* scene);
 
+/* References inside the scene data (the reference kernel follows them unchecked: clCreateBuffer copies ints, nothing validates them):
+ *   - octree branch values and BVH node links are checked on upload (CHUNKY_E_INVALID: outside the array, cyclic, deeper than 64);
+ *   - an octree leaf whose block pointer lies beyond the block palette renders as air;
+ *   - a block whose model pointer, primitive count or material pointers leave their palettes never intersects, like a block of
+ *     unknown model type (K/block.h:44-47);
+ *   - an entity BVH whose leaves leave the triangle palette, or whose triangles' materials leave the material palette, makes
+ *     chunky_render_passes / _run / _preview fail with CHUNKY_E_INVALID.
+ * Well-formed data is unaffected.  The palettes may arrive in any order; the checks run when a render call first sees them together. */
 /* octreeData after the leaf remap of ClSceneLoader.java:52-63 + octreeDepth (getOctreeData/getOctreeDepth) */
 int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree, int64_t n_ints, int depth);
 /* Same, from Chunky's raw PackedOctree.treeData + blockMapping: performs the remap
