@@ -46,7 +46,8 @@ def _needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [HEADER]
+    # the sources (files only: csrc/build/ holds objects and tools that are written after the link)
+    deps = [p for p in (os.path.join(CSRC, f) for f in os.listdir(CSRC)) if os.path.isfile(p)] + [HEADER]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
