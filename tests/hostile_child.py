@@ -56,6 +56,9 @@ def main(seed0, count):
                 r = HipPathTracingRenderer(loader, bad.width, bad.height)
                 r.set_camera(bad.projector_type, bad.camera)
                 r.set_option(native.OPT_KERNEL, variant)
+                if variant == 0 and it % 3 == 0:   # the extended integrator reads the emitter list and material word 5 as well
+                    r.set_option(native.OPT_EMITTER_NEE, 1)
+                    r.set_option(native.OPT_BSDF, 1)
                 try:
                     r.render_passes(native.java_random_ints(2))
                     r.read()
