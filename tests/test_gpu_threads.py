@@ -64,6 +64,35 @@ def test_many_threads_one_context(gpu_instance, port):
 
 
 @pytest.mark.gpu
+def test_many_threads_one_group(port):
+    """the same on a group context (three members behind one handle): every call fans out under the group's lock"""
+    from chunkyclplugin_amd.renderer import RendererInstance
+    group = RendererInstance.group([0, 0, 0])
+    seeds = scenes.java_random_ints(2)
+    scs = [gs.make(n).with_view(48 + 16 * i, 32 + 8 * i) for i, n in enumerate(["indoor", "entities", "outdoor", "indoor"])]
+    want = [port.render_passes(sc, seeds) for sc in scs]
+    got = [None] * len(scs)
+
+    def worker(i):
+        def go():
+            for _ in range(3):
+                loader = HipSceneLoader(group)
+                loader.load_packed(scs[i])
+                r = HipPathTracingRenderer(loader, scs[i].width, scs[i].height)
+                r.set_camera(scs[i].projector_type, scs[i].camera)
+                r.render_passes(seeds, sync=False)
+                got[i] = r.read()
+                r.close()
+                loader.close()
+        return go
+
+    run_threads([worker(i) for i in range(len(scs))])
+    for i in range(len(scs)):
+        np.testing.assert_array_equal(got[i].view(np.uint32), want[i].view(np.uint32))
+    group.close()
+
+
+@pytest.mark.gpu
 def test_camera_thread_beside_the_pass_loop(gpu_instance, port):
     """render() on one thread while another keeps installing the camera (the regenerating ForkJoin task, ClCamera.java:99-104) and
     asking for previews; the camera it installs is the same one, so the image must be the oracle's"""
