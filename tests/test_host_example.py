@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def host_example(tmp_path_factory):
-    native.build()
+    native.lib()   # (builds the library only where it is missing)
     exe = str(tmp_path_factory.mktemp("host") / "host_example")
     cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host_example.cpp"),
            "-o", exe, "-L" + native.PKG_DIR, "-lchunky_hip", "-Wl,-rpath," + native.PKG_DIR, "-Wl,--allow-shlib-undefined"]

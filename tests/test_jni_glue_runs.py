@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def fake_jvm(tmp_path_factory):
-    native.build()
+    native.lib()   # (builds the library only where it is missing)
     exe = str(tmp_path_factory.mktemp("jvm") / "fake_jvm")
     cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
            os.path.join(ROOT, "tests", "jni_stub", "fake_jvm.cpp"), os.path.join(native.CSRC, "jni_glue.cpp"),
