@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +25,14 @@ using namespace chunky;
 
 static_assert(sizeof(chunky_hit_record) == sizeof(HitRecord), "record layouts must agree");
 static_assert(CHUNKY_MAX_TRACES == kMaxTraces, "trace capacity must agree");
+
+// placement of the entity-BVH records (relayout_bvh_records): records in the breadth-first top, records per treelet; 0 = off
+#ifndef CHUNKY_BVH_TOP_RECORDS
+#define CHUNKY_BVH_TOP_RECORDS 0
+#endif
+#ifndef CHUNKY_BVH_TREELET_RECORDS
+#define CHUNKY_BVH_TREELET_RECORDS 0
+#endif
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local std::string tls_error;
@@ -52,6 +61,7 @@ struct chunky_ctx {
     void* gamma_table = nullptr;  // 256 floats: the byte thresholds of the GAMMA / ACES tone maps (gamma_thresholds)
     // chunky_group_create: one member context per GPU; this object then only carries the lock and fans calls out
     std::vector<chunky_ctx*> members;
+    std::vector<int> peer_status;  // per member: how its read-back copies reach member 0 (chunky_group_peer_status)
 };
 
 struct DevBuf {
@@ -117,6 +127,7 @@ struct chunky_render {
     ShardView shard{0, 1, 256, 0};
     DevBuf own_fb, work_counter;
     DevBuf staging;  // render_pool: one launch's samples, [tile of 256 slots][pass][slot][3] floats
+    DevBuf block_list;  // block shards under a kernel without the block mapping: this rank's pixels (ShardView::list)
     float* fb = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // timing brackets of enqueued launches
     std::vector<hipEvent_t> free_events;
@@ -139,6 +150,19 @@ struct chunky_render {
 };
 
 constexpr size_t kStagingBytes = (size_t)8 << 30;  // 8 GiB: 1920x1080 x 256 passes is 6.4 GB (of 288)
+
+// The pixels of a block shard (tile 0) in block order, padding left out: what launch_fallback's kernels render when
+// render_pool does not apply to a sharded target (same ownership rule as pool_slot_gid, so the gather finds every pixel).
+static std::vector<int32_t> block_pixel_list(int width, int height, const ShardView& t) {
+    std::vector<int32_t> out;
+    const int bw = (width + 15) / 16, bh = (height + 15) / 16;
+    for (int64_t b = t.rank; b < (int64_t)bw * bh; b += t.world) {
+        const int bx = (int)(b % bw) * 16, by = (int)(b / bw) * 16;
+        for (int y = by; y < by + 16 && y < height; y++)
+            for (int x = bx; x < bx + 16 && x < width; x++) out.push_back(y * width + x);
+    }
+    return out;
+}
 
 static int n_local_slots(int width, int height, const ShardView& t) {
     const int n_pixels = width * height;
@@ -207,12 +231,22 @@ extern "C" int chunky_group_create(const int* devices, int n, chunky_ctx** out) 
     g->name = g->members[0]->name;
     // the read-back exchange copies member i's blocks into member 0's memory: direct (xGMI) where peer access exists, staged
     // by the runtime where it does not — failing to enable it is not an error
+    g->peer_status.assign((size_t)n, CHUNKY_PEER_LOCAL);
     for (int i = 1; i < n; i++) {
         if (devices[i] == devices[0]) continue;
         int can = 0;
-        if (hipSetDevice(devices[i]) == hipSuccess && hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can)
-            (void)hipDeviceEnablePeerAccess(devices[0], 0);
-        (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled is fine
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e == hipSuccess) e = hipDeviceCanAccessPeer(&can, devices[i], devices[0]);
+        if (e == hipSuccess && !can) {
+            g->peer_status[(size_t)i] = CHUNKY_PEER_STAGED;
+        } else if (e == hipSuccess) {
+            e = hipDeviceEnablePeerAccess(devices[0], 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+            g->peer_status[(size_t)i] = e == hipSuccess ? CHUNKY_PEER_DIRECT : -(int)e;
+        } else {
+            g->peer_status[(size_t)i] = -(int)e;
+        }
+        (void)hipGetLastError();
     }
     *out = g.release();
     return CHUNKY_OK;
@@ -221,6 +255,16 @@ extern "C" int chunky_group_create(const int* devices, int n, chunky_ctx** out) 
 extern "C" int chunky_group_size(chunky_ctx* ctx) {
     if (!ctx) return fail(CHUNKY_E_INVALID, "chunky_group_size: NULL context");
     return ctx->members.empty() ? 1 : (int)ctx->members.size();
+}
+
+extern "C" int chunky_group_peer_status(chunky_ctx* ctx, int* out, int n) {
+    if (!ctx || !out || n < chunky_group_size(ctx)) return fail(CHUNKY_E_INVALID, "chunky_group_peer_status: need room for %d members", ctx ? chunky_group_size(ctx) : 0);
+    if (ctx->members.empty()) {
+        out[0] = CHUNKY_PEER_LOCAL;
+        return CHUNKY_OK;
+    }
+    for (size_t i = 0; i < ctx->members.size(); i++) out[i] = ctx->peer_status[i];
+    return CHUNKY_OK;
 }
 
 extern "C" int chunky_group_device(chunky_ctx* ctx, int i) {
@@ -712,6 +756,98 @@ static int rebuild_derived(chunky_scene* s) {
 // -1 - (first triangle record << 6 | count) for a leaf.  The walk order, the tests and the arithmetic stay the reference's.
 // Returns false (no records: the packed arrays are walked as they are) when something does not fit: a leaf of more than
 // 63 triangles, a triangle pointer outside the palette, a material pointer that is not a whole material.
+// Placement of the inner records of one BVH (records [lo, hi) of bvh_rec, root reference *root): the first `top` records
+// breadth-first from the root (the levels every walk crosses, contiguous), then every subtree below that cut as depth-first
+// TREELETS of at most `treelet` records, each treelet breadth-first from its own root — a walker that enters a treelet finds
+// its next few visits in the same 1–2 KB.  References are renumbered; nothing else changes.
+static void relayout_bvh_records(std::vector<int32_t>* bvh_rec, size_t lo, size_t hi, int* root, int top, int treelet) {
+    if (hi <= lo || *root < 0) return;
+    const size_t n = hi - lo;
+    std::vector<int32_t> order;  // order[k] = old index of the record that moves to lo + k
+    order.reserve(n);
+    auto rec = [&](int32_t idx) { return &(*bvh_rec)[(size_t)idx * 16]; };
+    std::vector<int32_t> frontier{*root};
+    {   // the top, breadth-first
+        size_t head = 0;
+        while (head < frontier.size() && order.size() < (size_t)top) {
+            const int32_t at = frontier[head++];
+            order.push_back(at);
+            for (int c = 0; c < 2; c++)
+                if (rec(at)[c] >= 0) frontier.push_back(rec(at)[c]);
+        }
+        frontier.erase(frontier.begin(), frontier.begin() + (ptrdiff_t)head);
+    }
+    // below the cut: treelets, depth-first (a stack of treelet roots; the first child's treelet follows its parent's)
+    std::vector<int32_t> roots(frontier.rbegin(), frontier.rend()), members, next;
+    while (!roots.empty()) {
+        members.assign(1, roots.back());
+        roots.pop_back();
+        next.clear();
+        for (size_t head = 0; head < members.size(); head++) {
+            const int32_t at = members[head];
+            order.push_back(at);
+            for (int c = 0; c < 2; c++) {
+                const int32_t r = rec(at)[c];
+                if (r < 0) continue;
+                if (members.size() < (size_t)treelet) members.push_back(r); else next.push_back(r);
+            }
+        }
+        roots.insert(roots.end(), next.rbegin(), next.rend());
+    }
+    if (order.size() != n) return;  // (cannot happen: every record of the range hangs under the root exactly once)
+    std::vector<int32_t> where(n), moved(n * 16);
+    for (size_t k = 0; k < n; k++) where[(size_t)order[k] - lo] = (int32_t)(lo + k);
+    for (size_t k = 0; k < n; k++) {
+        const int32_t* from = rec(order[k]);
+        int32_t* to = &moved[k * 16];
+        std::copy(from, from + 16, to);
+        for (int c = 0; c < 2; c++)
+            if (to[c] >= 0) to[c] = where[(size_t)to[c] - lo];
+    }
+    std::copy(moved.begin(), moved.end(), bvh_rec->begin() + (ptrdiff_t)(lo * 16));
+    *root = where[(size_t)*root - lo];
+}
+
+// Triangle records in the order in which the inner records (as placed) refer to their leaves, so that the leaves under one
+// treelet lie together.  A leaf shared by several references moves once.
+static void reorder_triangles(std::vector<int32_t>* bvh_rec, std::vector<int32_t>* tri_rec, int* world_root, int* actor_root) {
+    const size_t n_tri = tri_rec->size() / 20;
+    std::vector<int32_t> moved;
+    moved.reserve(tri_rec->size());
+    std::vector<int32_t> first_at(n_tri + 1, -1);  // old first triangle of a leaf -> new
+    auto move_leaf = [&](int32_t* ref) {
+        if (*ref >= 0) return;
+        const int32_t l = -1 - *ref, first = l >> 6, count = l & 63;
+        if (count == 0 || (size_t)first + (size_t)count > n_tri) return;
+        if (first_at[(size_t)first] < 0) {
+            first_at[(size_t)first] = (int32_t)(moved.size() / 20);
+            moved.insert(moved.end(), tri_rec->begin() + (ptrdiff_t)first * 20, tri_rec->begin() + (ptrdiff_t)(first + count) * 20);
+        }
+        *ref = -1 - ((first_at[(size_t)first] << 6) | count);
+    };
+    move_leaf(world_root);
+    move_leaf(actor_root);
+    for (size_t k = 0; k < bvh_rec->size() / 16; k++) {
+        move_leaf(&(*bvh_rec)[k * 16]);
+        move_leaf(&(*bvh_rec)[k * 16 + 1]);
+    }
+    tri_rec->swap(moved);  // every reference now points into `moved`
+}
+
+// top / treelet sizes of relayout_bvh_records; CHUNKY_BVH_LAYOUT="top,treelet" overrides them for tuning runs ("0,0" = the
+// plain depth-first order of round 2)
+static void bvh_layout_params(int* top, int* treelet) {
+    *top = CHUNKY_BVH_TOP_RECORDS;
+    *treelet = CHUNKY_BVH_TREELET_RECORDS;
+    if (const char* e = getenv("CHUNKY_BVH_LAYOUT")) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0) {
+            *top = a;
+            *treelet = b;
+        }
+    }
+}
+
 static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_rec, std::vector<int32_t>* tri_rec, int* world_root,
                               int* actor_root) {
     const std::vector<int32_t>&T = s->host_trigs, &M = s->host_materials;
@@ -783,7 +919,16 @@ static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_r
     bvh_rec->clear();
     tri_rec->clear();
     if (!build(s->host_world_bvh, s->world_empty, world_root)) return false;
+    const size_t world_records = bvh_rec->size() / 16;
     if (!build(s->host_actor_bvh, s->actor_empty, actor_root)) return false;
+    // where the records sit (addresses only: the walk's order, tests and arithmetic do not see it)
+    int top = 0, treelet = 0;
+    bvh_layout_params(&top, &treelet);
+    if (treelet > 1) {
+        relayout_bvh_records(bvh_rec, 0, world_records, world_root, top, treelet);
+        relayout_bvh_records(bvh_rec, world_records, bvh_rec->size() / 16, actor_root, top, treelet);
+        reorder_triangles(bvh_rec, tri_rec, world_root, actor_root);
+    }
     return true;
 }
 
@@ -1130,6 +1275,8 @@ extern "C" int chunky_render_set_shard(chunky_render* r, int rank, int world, in
     if (world < 1 || rank < 0 || rank >= world || tile < 0) return fail(CHUNKY_E_INVALID, "set_shard: rank %d / world %d / tile %d", rank, world, tile);
     ShardView t{rank, world, tile, 0};
     t.n_local = n_local_slots(r->width, r->height, t);
+    if (r->shard.list) HIP_TRY(hipStreamSynchronize(r->ctx->stream));  // queued launches may still read the old list
+    r->block_list.release();
     r->shard = t;
     r->launch_cap = 0;  // the share changed: so does what a launch can stage
     return CHUNKY_OK;
@@ -1208,6 +1355,16 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
     if (r->pending.size() > 4096)
         if (int rc = collect_timing(r)) return rc;
     if (r->shard.n_local <= 0) return CHUNKY_OK;  // this rank (or group member) owns no tile of so small an image: nothing to render
+    if (r->shard.world != 1 && r->shard.tile == 0 && !r->shard.list &&
+        !pool_kernel_applies(r->kernel_variant, S, r->opts, r->work_counter.p != nullptr)) {
+        // a share of 16 x 16 blocks (every group member has one) and a scene / option set render_pool does not take: the
+        // fallback kernels render the same pixels from a list
+        const std::vector<int32_t> px = block_pixel_list(r->width, r->height, r->shard);
+        if (px.empty()) return CHUNKY_OK;
+        HIP_TRY(r->block_list.upload(px.data(), px.size() * 4, r->ctx->stream));
+        r->shard.list = (const int*)r->block_list.p;
+        r->shard.n_list = (int)px.size();
+    }
     if (r->launch_cap <= 0) r->launch_cap = launch_pass_cap(r, kStagingBytes);
     for (int done = 0; done < n;) {
         PassSeeds ps;
@@ -1434,8 +1591,14 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
     if (!r || !r->ctx) return fail(CHUNKY_E_INVALID, "NULL render");
     if (!sample_buffer || !scene_spp) return fail(CHUNKY_E_INVALID, "render_run: NULL buffer");
     if (merge_interval < 1) merge_interval = 1024;  // OpenClPathTracingRenderer.java:158
-    const chunky_run_callbacks none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const chunky_run_callbacks& cb = callbacks ? *callbacks : none;
+    // the caller's struct may be older (shorter) than this library's: copy what it holds, the rest stays NULL
+    chunky_run_callbacks cb{};
+    if (callbacks) {
+        const size_t have = callbacks->struct_size;
+        if (have < offsetof(chunky_run_callbacks, progress) || have % sizeof(void*) != 0)
+            return fail(CHUNKY_E_INVALID, "render_run_ex: callbacks->struct_size %zu (set it to sizeof(chunky_run_callbacks))", have);
+        memcpy(&cb, callbacks, have < sizeof cb ? have : sizeof cb);
+    }
     const int64_t n = (int64_t)r->width * r->height * 3;
     std::vector<float> pass_buffer((size_t)n);
     JavaRandom rnd(0);                 // :95
@@ -1520,7 +1683,7 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
 
 extern "C" int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_spp, int32_t target_spp,
                                  int32_t merge_interval, chunky_post_render_fn post_render, void* user) {
-    const chunky_run_callbacks cb{post_render, nullptr, nullptr, nullptr, nullptr, user, nullptr};
+    const chunky_run_callbacks cb{sizeof(chunky_run_callbacks), post_render, nullptr, nullptr, nullptr, nullptr, user, nullptr};
     return chunky_render_run_ex(r, sample_buffer, scene_spp, target_spp, merge_interval, &cb);
 }
 

@@ -129,6 +129,18 @@ JNIEXPORT jint JNICALL J(groupSize)(JNIEnv* env, jclass, jlong ctx) {
     if (n < 0) throw_last(env);
     return n;
 }
+JNIEXPORT void JNICALL J(groupPeerStatus)(JNIEnv* env, jclass, jlong ctx, jintArray out) {
+    const int n = chunky_group_size((chunky_ctx*)ctx);
+    if (n < 0) {
+        throw_last(env);
+        return;
+    }
+    if (bad_length(env, out, n, "groupPeerStatus")) return;
+    jint* p = env->GetIntArrayElements(out, nullptr);
+    int rc = chunky_group_peer_status((chunky_ctx*)ctx, (int*)p, n);
+    env->ReleaseIntArrayElements(out, p, rc == CHUNKY_OK ? 0 : JNI_ABORT);
+    CHECK(rc);
+}
 JNIEXPORT void JNICALL J(shutdown)(JNIEnv* env, jclass, jlong ctx) { CHECK(chunky_shutdown((chunky_ctx*)ctx)); }
 JNIEXPORT jlong JNICALL J(sceneCreate)(JNIEnv* env, jclass, jlong ctx) {
     chunky_scene* s = nullptr;
@@ -240,7 +252,7 @@ JNIEXPORT jint JNICALL J(renderRun)(JNIEnv* env, jclass, jlong r, jint width, ji
     std::vector<double> buffer((size_t)3 * width * height);
     env->GetDoubleArrayRegion(samples, 0, (jsize)buffer.size(), buffer.data());
     Run run{env, listener, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, samples, &buffer, false};
-    chunky_run_callbacks cb{nullptr, nullptr, cb_merged, nullptr, nullptr, &run, nullptr};
+    chunky_run_callbacks cb{sizeof(chunky_run_callbacks), nullptr, nullptr, cb_merged, nullptr, nullptr, &run, nullptr};
     if (listener) {
         jclass cls = env->GetObjectClass(listener);
         run.post_render = env->GetMethodID(cls, "postRender", "()Z");

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace chunky {
 
 struct SceneView;
@@ -17,6 +19,10 @@ constexpr int kBvhStackEntries = 64;  // K/bvh.h:38
 // indices dealt round-robin over `world` ranks; n_local = pixel slots owned by `rank`.
 struct ShardView {
     int rank, world, tile, n_local;
+    // block shards (tile 0) under a kernel that cannot map 16 x 16 blocks itself (launch_fallback): the rank's pixels, in
+    // block order, as an explicit list on the device (capi.hip block_pixel_list); null otherwise
+    const int* list = nullptr;
+    int n_list = 0;
 };
 
 // Layout shared with include/chunky_hip.h (chunky_hit_record) and oracle/oracle_scene.h.
@@ -60,6 +66,26 @@ inline size_t staging_floats(const ShardView& T, int width, int height, int n_pa
     return 3 * (size_t)pool_tile_count(T, width, height) * 256 * (size_t)n_passes;
 }
 
+// compute units of the CURRENT device (cached per device index: members of a group and threads of a host may sit on different GPUs)
+inline hipError_t current_device_cus(int* n_cu) {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool slot = dev >= 0 && dev < 64;
+    int n = slot ? cached[dev].load(std::memory_order_relaxed) : 0;
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) return e;
+        n = prop.multiProcessorCount;
+        if (slot) cached[dev].store(n, std::memory_order_relaxed);
+    }
+    *n_cu = n;
+    return hipSuccess;
+}
+// true when launch_render will run render_pool for this scene / option set (else launch_fallback: render_waves, render_lanes)
+bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, bool have_queue_and_staging);
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream,
                          KernelChoice* chosen = nullptr, float* staging = nullptr);

@@ -196,6 +196,7 @@ DEV f3 sample_path(const SceneView& S, const CameraView& C, const RenderOpts& O,
 DEV int shard_gid(const ShardView& T, int local) {
     // local pixel slot -> global pixel index: tiles of T.tile consecutive gids dealt round-robin
     if (T.world == 1) return local;
+    if (T.list) return T.list[local];  // block shards under a kernel without the block mapping: the rank's pixels listed
     int t = local / T.tile, w = local - t * T.tile;
     return (t * T.world + T.rank) * T.tile + w;
 }

@@ -513,13 +513,8 @@ hipError_t launch_fallback(int variant, const SceneView& S, const CameraView& C,
     const int tree = use_wide(variant, S) ? -1 : 0;
     if (!(variant & 2) && work_counter) {
         // wave-scheduled persistent kernel: one resident grid, lanes pull pixels from a counter
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-            n_cu = prop.multiProcessorCount;
-        }
+        int n_cu = 0;
+        if (hipError_t e = current_device_cus(&n_cu)) return e;
         const size_t stack = stack_lds_bytes(S, block);
         size_t lds = stack;
         // lanes per pixel (see next_sample): 8; 16 or 32 when this GPU owns few pixels (multi-GPU tile split: the fewer

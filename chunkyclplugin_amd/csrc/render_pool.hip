@@ -677,13 +677,8 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
                               const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
                               float* staging) {
     const int block = 256;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        n_cu = prop.multiProcessorCount;
-    }
+    int n_cu = 0;
+    if (hipError_t e = current_device_cus(&n_cu)) return e;
     if (T.n_local <= 0 || P.n <= 0) return hipSuccess;
     const bool stats = (variant & 4) != 0;
     int tree = tree_form(variant, S);
@@ -766,16 +761,26 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
                        C.width * C.height, C.width, n_tiles * kSampleTile, P.n, P.first_spp);
     return hipGetLastError();
 }
-hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
-                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
-                         float* staging) {
+bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, bool have_queue_and_staging) {
     const bool any_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
     // render_pool: always without entity BVHs; with them when they could be re-laid out (rt_device.hpp bvh_rec / tri_rec)
     // (its 7-word parked record counts march steps in 16 bits: a larger draw depth runs render_waves)
     const bool steps_fit = any_bvh || opts_extended(O) || O.draw_depth <= 65535;
-    if (!(variant & 2) && !(variant & 8) && work_counter && staging && steps_fit && (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1))))
+    return !(variant & 2) && !(variant & 8) && have_queue_and_staging && steps_fit &&
+           (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1)));
+}
+hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
+                         const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
+                         float* staging) {
+    if (pool_kernel_applies(variant, S, O, work_counter && staging))
         return launch_pool(variant, S, C, O, T, P, res, work_counter, stream, chosen, staging);
-    if (T.world != 1 && T.tile == 0) return hipErrorNotSupported;  // shards of 16 x 16 blocks exist in render_pool only
+    if (T.world != 1 && T.tile == 0) {
+        // shards of 16 x 16 blocks are mapped by render_pool only: the other kernels take the rank's pixels as a list
+        if (!T.list) return hipErrorNotSupported;
+        ShardView F = T;
+        F.n_local = T.n_list;
+        return launch_fallback(variant, S, C, O, F, P, res, work_counter, stream, chosen);
+    }
     return launch_fallback(variant, S, C, O, T, P, res, work_counter, stream, chosen);
 }
 

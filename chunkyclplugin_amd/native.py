@@ -28,6 +28,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("material", "<i4"), ("distance", "<f4"), 
 PALETTE_BLOCK, PALETTE_MATERIAL, PALETTE_AABB, PALETTE_QUAD, PALETTE_TRIG = range(5)
 BVH_WORLD, BVH_ACTOR = 0, 1
 OPT_DRAW_DEPTH, OPT_MAX_DEPTH, OPT_EMITTER_SCALE, OPT_KERNEL, OPT_SUN_SAMPLING, OPT_EMITTERS, OPT_BSDF, OPT_EMITTER_NEE = range(8)
+PEER_LOCAL, PEER_DIRECT, PEER_STAGED = 0, 1, 2
 E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_ABORTED = -1, -2, -3, -4, -5
 
 
@@ -103,7 +104,7 @@ REGEN_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 class RunCallbacks(C.Structure):
     """chunky_run_callbacks (include/chunky_hip.h)."""
-    _fields_ = [("post_render", POST_RENDER_FN), ("progress", PROGRESS_FN), ("merged", PROGRESS_FN),
+    _fields_ = [("struct_size", C.c_size_t), ("post_render", POST_RENDER_FN), ("progress", PROGRESS_FN), ("merged", PROGRESS_FN),
                 ("save_event", SAVE_EVENT_FN), ("regenerate_camera", REGEN_FN), ("user", C.c_void_p),
                 ("poll_gate", POST_RENDER_FN)]
 
@@ -125,6 +126,7 @@ def lib() -> C.CDLL:
             "chunky_group_create": [vp, C.c_int, C.POINTER(vp)],
             "chunky_group_size": [vp],
             "chunky_group_device": [vp, C.c_int],
+            "chunky_group_peer_status": [vp, vp, C.c_int],
             "chunky_scene_create": [vp, C.POINTER(vp)],
             "chunky_scene_destroy": [vp],
             "chunky_scene_set_octree": [vp, vp, i64, C.c_int],

@@ -60,6 +60,14 @@ class RendererInstance:
     def group_size(self) -> int:
         return native.lib().chunky_group_size(self._h)
 
+    def peer_status(self) -> list:
+        """chunky_group_peer_status: per member, how its share of a read-back reaches member 0 — native.PEER_LOCAL /
+        PEER_DIRECT (xGMI) / PEER_STAGED, or a negated HIP error code when enabling peer access failed."""
+        n = self.group_size()
+        out = (C.c_int * n)()
+        check(native.lib().chunky_group_peer_status(self._h, out, n))
+        return list(out)
+
     @staticmethod
     def device_count() -> int:
         return native.lib().chunky_device_count()
@@ -280,7 +288,7 @@ class HipPathTracingRenderer:
         assert sample_buffer.dtype == np.float64 and sample_buffer.size == self.width * self.height * 3
         spp = C.c_int32(scene_spp)
         cb = native.RunCallbacks(
-            native.POST_RENDER_FN((lambda _u: 1 if self.post_render() else 0) if self.post_render else 0),
+            C.sizeof(native.RunCallbacks), native.POST_RENDER_FN((lambda _u: 1 if self.post_render() else 0) if self.post_render else 0),
             native.PROGRESS_FN((lambda _u, s: progress(s)) if progress else 0),
             native.PROGRESS_FN((lambda _u, s: merged(s)) if merged else 0),
             native.SAVE_EVENT_FN((lambda _u, s: int(save_event(s))) if save_event else 0),

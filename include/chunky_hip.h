@@ -20,6 +20,7 @@
 #ifndef CHUNKY_HIP_H
 #define CHUNKY_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -59,6 +60,15 @@ int chunky_group_create(const int* devices, int n, chunky_ctx** out);
 int chunky_group_size(chunky_ctx* ctx);
 /* Device index of member i. */
 int chunky_group_device(chunky_ctx* ctx, int i);
+/* How each member's share of a read-back reaches member 0, decided once in chunky_group_create (no reference counterpart; the
+ * reference is single-device): out[i] = CHUNKY_PEER_LOCAL (member 0 itself, or a member on member 0's device), CHUNKY_PEER_DIRECT
+ * (hipDeviceEnablePeerAccess succeeded: hipMemcpyPeerAsync writes member 0's memory over xGMI), CHUNKY_PEER_STAGED (the devices
+ * report no peer access: the runtime stages the copy through the host), or -(hipError_t) when enabling it failed (the copy still
+ * works, staged).  n = room in out, at least chunky_group_size(ctx). */
+#define CHUNKY_PEER_LOCAL 0
+#define CHUNKY_PEER_DIRECT 1
+#define CHUNKY_PEER_STAGED 2
+int chunky_group_peer_status(chunky_ctx* ctx, int* out, int n);
 const char* chunky_last_error(void);
 /* Library identity: "chunky-hip <version> gfx950". */
 const char* chunky_version(void);
@@ -240,8 +250,12 @@ int chunky_render_run(chunky_render* r, double* sample_buffer, int32_t* scene_sp
  *                     camera-ray table on a worker while passes run (:146-148, ClCamera.java:72-104).  The hook may
  *                     call chunky_render_set_camera (from this or any other thread: the context mutex is the
  *                     reference's renderLock) to install a fresh table; passes already queued finish with the old one.
- * chunky_render_run(..., post_render, user) is chunky_render_run_ex with only post_render set. */
+ * chunky_render_run(..., post_render, user) is chunky_render_run_ex with only post_render set.
+ * struct_size = sizeof(chunky_run_callbacks) as the CALLER was compiled: members are appended over time, and the library reads
+ * only those the caller's struct holds (a host built against an older header keeps working; 0 or a size that cuts a member in
+ * half is CHUNKY_E_INVALID). */
 typedef struct chunky_run_callbacks {
+    size_t struct_size;
     int (*post_render)(void* user);
     void (*progress)(void* user, int32_t scene_spp);
     void (*merged)(void* user, int32_t sample_spp);

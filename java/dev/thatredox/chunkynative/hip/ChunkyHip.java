@@ -26,6 +26,15 @@ public class ChunkyHip implements Plugin {
             int[] devices = new int[ids.length];
             for (int i = 0; i < ids.length; i++) devices[i] = Integer.parseInt(ids[i].trim());
             ctx = devices.length == 1 ? HipNative.init(devices[0]) : HipNative.groupCreate(devices);
+            if (devices.length > 1) {
+                // a member without peer access to member 0 still works (its read-backs are staged through the host): say so
+                int[] peers = new int[devices.length];
+                HipNative.groupPeerStatus(ctx, peers);
+                for (int i = 1; i < peers.length; i++)
+                    if (peers[i] != HipNative.PEER_DIRECT && peers[i] != HipNative.PEER_LOCAL)
+                        Log.warn("ChunkyHip: GPU " + devices[i] + " has no peer access to GPU " + devices[0] + " (status "
+                                + peers[i] + "): its share of every read-back is staged through the host.");
+            }
         } catch (UnsatisfiedLinkError | RuntimeException e) {
             Log.error("Failed to load ChunkyHip. Could not load libchunky_hip or no gfx950 device.", e);
             return;

@@ -24,6 +24,10 @@ public final class HipNative {
      *  round-robin, one gather per read-back); every other method takes the handle like init's. */
     public static native long groupCreate(int[] devices);
     public static native int groupSize(long ctx);
+    /** chunky_group_peer_status: out[i] = how member i's read-back share reaches member 0 — PEER_LOCAL, PEER_DIRECT (xGMI),
+     *  PEER_STAGED (no peer access between the two devices), or a negated HIP error when enabling peer access failed.
+     *  out.length must be groupSize(ctx). */
+    public static native void groupPeerStatus(long ctx, int[] out);
     public static native void shutdown(long ctx);
 
     // scene — replaces ClIntBuffer / ClTextureLoader / ClSky uploads (ClSceneLoader.java:52-150)
@@ -78,4 +82,5 @@ public final class HipNative {
 
     public static final int PALETTE_BLOCK = 0, PALETTE_MATERIAL = 1, PALETTE_AABB = 2, PALETTE_QUAD = 3, PALETTE_TRIG = 4;
     public static final int BVH_WORLD = 0, BVH_ACTOR = 1;
+    public static final int PEER_LOCAL = 0, PEER_DIRECT = 1, PEER_STAGED = 2;
 }

@@ -14,6 +14,7 @@
 // the kernel launchers live in the other translation units; nothing under test reaches them
 namespace chunky {
 hipError_t launch_render(int, const SceneView&, const CameraView&, const RenderOpts&, const ShardView&, const PassSeeds&, float*, int*, hipStream_t, KernelChoice*, float*) { return hipErrorNotSupported; }
+bool pool_kernel_applies(int, const SceneView&, const RenderOpts&, bool) { return false; }
 hipError_t launch_gather(bool, const ShardView&, int, int, float*, float*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_trace_records(int, const SceneView&, const CameraView&, const RenderOpts&, int, const int*, int, HitRecord*, int*, float*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_preview(int, const SceneView&, const CameraView&, const RenderOpts&, int*, hipStream_t) { return hipErrorNotSupported; }
@@ -173,8 +174,24 @@ static bool links_sound(const std::vector<int32_t>& N) {  // chunky_scene_set_bv
     return true;
 }
 
+// the tree the records describe, independent of where they sit: depth-first, an inner record's twelve box words then its two
+// subtrees, a leaf's count and triangle words
+static void canonical(const std::vector<int32_t>& nodes, const std::vector<int32_t>& tris, int32_t ref, std::vector<int32_t>* out, int depth = 0) {
+    if (depth > 80) return;
+    if (ref < 0) {
+        const int64_t leaf = -1 - (int64_t)ref, first = leaf >> 6, count = leaf & 63;
+        out->push_back((int32_t)count);
+        out->insert(out->end(), tris.begin() + first * 20, tris.begin() + (first + count) * 20);
+        return;
+    }
+    const int32_t* r = &nodes[(size_t)ref * 16];
+    out->insert(out->end(), r + 4, r + 16);
+    canonical(nodes, tris, r[0], out, depth + 1);
+    canonical(nodes, tris, r[1], out, depth + 1);
+}
+
 static int fuzz_bvh(int rounds) {
-    long long built = 0, unfit = 0, refused = 0;
+    long long built = 0, unfit = 0, refused = 0, relaid = 0;
     for (int r = 0; r < rounds; r++) {
         chunky_scene s;
         const int n_mats = 1 + (int)(rng() % 5);
@@ -217,8 +234,32 @@ static int fuzz_bvh(int rounds) {
         if (!ref_ok(wr) || !ref_ok(ar)) return fprintf(stderr, "round %d: dangling root\n", r), 1;
         for (int64_t t = 0; t < n_tri; t++)
             if (tris[(size_t)t * 20 + 7] < 0 || (size_t)tris[(size_t)t * 20 + 7] / 2 >= s.host_materials.size() / 6) return fprintf(stderr, "round %d: material index\n", r), 1;
+        // the same BVHs placed as a breadth-first top over treelets (relayout_bvh_records, tiny sizes so that every branch of
+        // it runs on these small trees): references resolve, and the tree they describe is the same tree
+        {
+            static const char* const layouts[] = {"3,4", "0,2", "1,1000", "1000,3", "2,1"};
+            setenv("CHUNKY_BVH_LAYOUT", layouts[r % 5], 1);
+            std::vector<int32_t> nodes2, tris2;
+            int wr2 = 0, ar2 = 0;
+            const bool ok2 = build_bvh_records(&s, &nodes2, &tris2, &wr2, &ar2);
+            unsetenv("CHUNKY_BVH_LAYOUT");
+            if (!ok2 || nodes2.size() != nodes.size() || tris2.size() != tris.size()) return fprintf(stderr, "round %d: re-layout changed the record counts\n", r), 1;
+            const int64_t n_tri2 = (int64_t)tris2.size() / 20;
+            for (int64_t i = 0; i < n_inner; i++)
+                for (int c = 0; c < 2; c++) {
+                    const int32_t ref = nodes2[(size_t)i * 16 + c];
+                    if (ref >= 0 ? ref >= n_inner : ((-1 - (int64_t)ref) >> 6) + ((-1 - (int64_t)ref) & 63) > n_tri2) return fprintf(stderr, "round %d: re-layout left a dangling reference\n", r), 1;
+                }
+            std::vector<int32_t> a, b;
+            canonical(nodes, tris, wr, &a);
+            canonical(nodes, tris, ar, &a);
+            canonical(nodes2, tris2, wr2, &b);
+            canonical(nodes2, tris2, ar2, &b);
+            if (a != b) return fprintf(stderr, "round %d: re-layout %s changed the tree\n", r, layouts[r % 5]), 1;
+            relaid++;
+        }
     }
-    printf("{\"bvh_rounds\": %d, \"records_built\": %lld, \"sound_but_unfit\": %lld, \"refused\": %lld}\n", rounds, built, unfit, refused);
+    printf("{\"bvh_rounds\": %d, \"records_built\": %lld, \"sound_but_unfit\": %lld, \"refused\": %lld, \"relayouts_same_tree\": %lld}\n", rounds, built, unfit, refused, relaid);
     return 0;
 }
 

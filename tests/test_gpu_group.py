@@ -161,3 +161,55 @@ def test_members_without_a_block_render_nothing(port):
     rg.close()
     lg.close()
     g3.close()
+
+
+@pytest.mark.parametrize("case", ["variant8", "variant1_entities", "draw_depth", "lanes"])
+def test_group_when_the_pool_kernel_does_not_apply(group3, gpu_instance, port, case):
+    """Every member of a group holds a share of 16 x 16 blocks, which render_pool maps itself.  Scenes / options it does not take
+    (variant bit 3 = round 1's kernel, bit 0 with entities = the packed BVH walk, a draw depth beyond its 16-bit step counter,
+    bit 1 = one lane per path) run the fallback kernels on the same pixels from a list (capi.hip block_pixel_list): the image
+    is still the one-context image and the oracle's."""
+    from oracle.binding import PortOptions
+    if case == "variant1_entities":
+        sc = gs.make("entities")
+    else:
+        sc = scenes.outdoor_world(chunks=4, height=64, seed=21, width=200, img_height=120, aabb_frac=0.05, quad_frac=0.03)
+    seeds = native.java_random_ints(5)
+    lg, rg = renderer_on(group3, sc)
+    l1, r1 = renderer_on(gpu_instance, sc)
+    depth = 256
+    for r in (rg, r1):
+        if case == "variant8":
+            r.set_option(native.OPT_KERNEL, 8)
+        elif case == "variant1_entities":
+            r.set_option(native.OPT_KERNEL, 1)
+        elif case == "lanes":
+            r.set_option(native.OPT_KERNEL, 2)
+        else:
+            depth = 70000
+            r.set_option(native.OPT_DRAW_DEPTH, depth)
+        r.render_passes(seeds[:3])
+        r.render_passes(seeds[3:], first_buffer_spp=3)
+    assert rg.kernel_info()["pool"] < 0, rg.kernel_info()  # the members did run a fallback kernel
+    got = rg.read()
+    np.testing.assert_array_equal(bits(got), bits(r1.read()))
+    with PortOptions(port, draw_depth=depth):
+        np.testing.assert_array_equal(bits(got), bits(port.render_passes(sc, seeds)))
+    # back to the default kernel on the same target: the share is mapped by render_pool again
+    rg.set_option(native.OPT_KERNEL, 0)
+    rg.set_option(native.OPT_DRAW_DEPTH, 256)
+    rg.reset()
+    rg.render_passes(seeds)
+    assert rg.kernel_info()["pool"] >= 0
+    np.testing.assert_array_equal(bits(rg.read()), bits(port.render_passes(sc, seeds)))
+    for x in (rg, r1, lg, l1):
+        x.close()
+
+
+def test_group_peer_status(group3, gpu_instance):
+    """chunky_group_peer_status: members that share member 0's device need no peer copy; a plain context reports one LOCAL entry."""
+    assert group3.peer_status() == [native.PEER_LOCAL] * 3
+    assert gpu_instance.peer_status() == [native.PEER_LOCAL]
+    import ctypes as C
+    out = (C.c_int * 2)()
+    assert native.lib().chunky_group_peer_status(group3._h, out, 2) == native.E_INVALID  # room for fewer members than the group has

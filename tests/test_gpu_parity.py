@@ -449,3 +449,55 @@ def test_aabb_plus_z_face_on_the_device(gpu_instance, port, variant):
     assert_radiance(r.read(), port.render_passes(sc, seeds), f"+z face image, variant {variant}")
     r.close()
     loader.close()
+
+
+def test_run_callbacks_of_an_older_host(gpu_instance, port):
+    """chunky_run_callbacks carries the caller's sizeof: a host compiled before `poll_gate` existed passes a shorter struct and
+    the library must not read past it; a size of 0, or one that cuts a member in half, is refused."""
+    import ctypes as C
+    sc = gs.make("outdoor").with_view(40, 24)
+    loader, r = make_renderer(gpu_instance, sc)
+    L = native.lib()
+    sample = np.zeros(sc.width * sc.height * 3, np.float64)
+    merges = []
+    keep = native.PROGRESS_FN(lambda _u, s: merges.append(s))
+
+    class Guarded(C.Structure):  # the real struct followed by a word the library would call if it read `poll_gate` regardless
+        _fields_ = [("cb", native.RunCallbacks), ("canary", C.c_void_p)]
+    g = Guarded()
+    g.cb.struct_size = native.RunCallbacks.poll_gate.offset   # the six-member struct of the previous header
+    g.cb.merged = keep
+    g.cb.poll_gate = C.cast(C.c_void_p(0xdeadbeef), native.POST_RENDER_FN)  # beyond struct_size: must never be called
+    spp = C.c_int32(0)
+    rc = L.chunky_render_run_ex(r._h, native.ptr(sample), C.byref(spp), 6, 4, C.cast(C.byref(g), C.POINTER(native.RunCallbacks)))
+    assert rc == 0 and spp.value == 6 and merges == [4, 6]
+    seeds = scenes.java_random_ints(6)
+    want = port.render_passes(sc, seeds[:4]).astype(np.float64)
+    want = (want * 4 + port.render_passes(sc, seeds[4:]).astype(np.float64) * 2) * (1.0 / 6)
+    np.testing.assert_array_equal(sample, want)
+    for bad in (0, 4, native.RunCallbacks.poll_gate.offset + 3):
+        g.cb.struct_size = bad
+        assert L.chunky_render_run_ex(r._h, native.ptr(sample), C.byref(spp), 8, 4, C.cast(C.byref(g), C.POINTER(native.RunCallbacks))) == native.E_INVALID
+    r.close()
+    loader.close()
+
+
+@pytest.mark.parametrize("layout", ["5,3", "0,2", "4096,32"])
+def test_entity_bvh_record_placement_is_invisible(gpu_instance, layout, monkeypatch):
+    """Where the entity-BVH records sit in memory (CHUNKY_BVH_LAYOUT: a breadth-first top over depth-first treelets,
+    capi.hip relayout_bvh_records) changes addresses only: image and per-trace records stay the reference's."""
+    g = np.load(os.path.join(GOLD, "entities.npz"))
+    sc = gs.make("entities")
+    monkeypatch.setenv("CHUNKY_BVH_LAYOUT", layout)
+    loader, r = make_renderer(gpu_instance, sc)
+    r.render_passes(g["seeds"])
+    assert r.kernel_info()["bvh"] and r.kernel_info()["pool"] > 0
+    np.testing.assert_array_equal(r.read().view(np.uint32), g["res"].view(np.uint32))
+    rec, cnt, _ = r.trace_records(int(g["seeds"][0]), gs.RECORD_GIDS)
+    np.testing.assert_array_equal(cnt, g["counts"])
+    for i in range(len(gs.RECORD_GIDS)):
+        n = int(cnt[i])
+        assert rec[i, :n]["material"].tolist() == g["records"][i, :n]["material"].tolist()
+        np.testing.assert_array_equal(rec[i, :n]["distance"].view(np.uint32), g["records"][i, :n]["distance"].view(np.uint32))
+    r.close()
+    loader.close()
