@@ -8,6 +8,9 @@ module; nothing under `chunkyclplugin_amd/` does.
              it does not travel to the GPU box).
 * `port()` — oracle/libchunky_port.so: oracle/port.c, the plain-C restatement (buildable
              anywhere with gcc).
+* `port_libm()` / `ref_libm()` — the same two on a second platform layer (glibc libm, unfused
+             vector builtins): they must agree bit for bit, which pins the restatement's logic
+             under builtins that do not come from rt_math.h.
 """
 from __future__ import annotations
 
@@ -315,6 +318,8 @@ def algorithmic_bytes(c: dict) -> float:
 
 _ref: Optional[RefLib] = None
 _port: Optional[PortLib] = None
+_port_libm: Optional[PortLib] = None
+_ref_libm: Optional[RefLib] = None
 
 
 def _make(target: str) -> None:
@@ -339,6 +344,31 @@ def ref(build: bool = True) -> Optional[RefLib]:
             return None
         _ref = RefLib(path)
     return _ref
+
+
+def port_libm(build: bool = True) -> PortLib:
+    """oracle/port.c built with -DPORT_LIBM: the restatement on the second platform layer (glibc libm, unfused dot / cross /
+    normalize — what ref_shim.cpp gives the compiled reference under REF_SHIM_LIBM)."""
+    global _port_libm
+    if _port_libm is None:
+        path = os.path.join(HERE, "libchunky_port_libm.so")
+        if build:
+            _make("port_libm")
+        _port_libm = PortLib(path)
+    return _port_libm
+
+
+def ref_libm(build: bool = True) -> Optional[RefLib]:
+    """The compiled reference on the second platform layer, or None where it cannot exist."""
+    global _ref_libm
+    if _ref_libm is None:
+        path = os.path.join(HERE, "_ref", "libchunky_ref_libm.so")
+        if build and os.path.isdir("/root/reference"):
+            _make("ref_libm")
+        if not os.path.exists(path):
+            return None
+        _ref_libm = RefLib(path)
+    return _ref_libm
 
 
 def port(build: bool = True) -> PortLib:

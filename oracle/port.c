@@ -15,10 +15,15 @@
  * It also counts the reference algorithm's access stream (BASELINE.md section 4 "algorithmic
  * bytes per sample"), which the roofline figure in bench.py is computed from.
  */
+#define _GNU_SOURCE /* sched_setaffinity, CPU_SET */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef __linux__
+#include <sched.h>
+#include <unistd.h>
+#endif
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -38,11 +43,32 @@ static inline v3 add3(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); 
 static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 mul3(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 scale3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+#ifndef PORT_LIBM
 static inline float dot3(v3 a, v3 b) { return rt_dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 static inline v3 cross3(v3 a, v3 b) {
     return V3(rt_cross_c(a.y, b.z, a.z, b.y), rt_cross_c(a.z, b.x, a.x, b.z), rt_cross_c(a.x, b.y, a.y, b.x));
 }
 static inline v3 normalize3(v3 a) { return scale3(a, rt_rlen3(a.x, a.y, a.z)); }
+#else
+/* PORT_LIBM (make port_libm -> libchunky_port_libm.so): this restatement on a SECOND platform layer — glibc's sinf / cosf /
+ * asinf / acosf / atan2f and unfused dot / cross / normalize, exactly the definitions oracle/ref_shim.cpp gives the compiled
+ * reference under REF_SHIM_LIBM (:53-125).  tests/test_platform_layer.py demands port_libm == ref_libm BIT FOR BIT: the
+ * restatement's LOGIC is then pinned to the reference's under builtins that do not come from rt_math.h. */
+#include <math.h>
+static inline float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cross3(v3 a, v3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline v3 normalize3(v3 a) {
+    float len = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return V3(a.x / len, a.y / len, a.z / len);
+}
+static inline void port_libm_sincos(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+#define rt_sincos port_libm_sincos
+#define rt_sin sinf
+#define rt_cos cosf
+#define rt_asin asinf
+#define rt_acos acosf
+#define rt_atan2 atan2f
+#endif
 
 /* ---------------------------------------------------------------- access-stream counters --- */
 typedef struct {
@@ -1026,28 +1052,73 @@ int port_render_passes(const OracleScene* s, const int32_t* seeds, int n_passes,
     return 0;
 }
 
-/* Same, over an explicit list of pixel indices (bench.py samples whole rows of a large image). */
+/* Timing runs (bench.py's cpu_baseline leg, tools/cpu_sweep.py): for the duration of one parallel region worker t binds itself
+ * to the t-th CPU the calling thread may use (Linux numbers the first hardware thread of every core before the second ones: up
+ * to the core count that is one worker per core), and gets its previous mask back at the end.  Without it the leg depends on
+ * where the scheduler happens to put (and keeps moving) the workers: on the 8-CPU build VM four unpinned workers ran at a
+ * quarter of the pinned rate.  Off by default. */
+static int g_pin_threads = 0;
+void port_set_pinning(int on) { g_pin_threads = on; }
+#if defined(__linux__) && defined(_OPENMP)
+typedef struct { int n; int cpu[1024]; } PinPlan;
+static void pin_plan(PinPlan* plan) {  /* by the calling thread, before the region */
+    plan->n = 0;
+    if (!g_pin_threads) return;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    for (int c = 0; c < CPU_SETSIZE && plan->n < 1024; c++)
+        if (CPU_ISSET(c, &allowed)) plan->cpu[plan->n++] = c;
+}
+static int pin_enter(const PinPlan* plan, cpu_set_t* saved) {  /* by every worker */
+    if (plan->n == 0 || sched_getaffinity(0, sizeof *saved, saved) != 0) return 0;
+    cpu_set_t one;
+    CPU_ZERO(&one);
+    CPU_SET(plan->cpu[omp_get_thread_num() % plan->n], &one);
+    return sched_setaffinity(0, sizeof one, &one) == 0;
+}
+static void pin_leave(int pinned, const cpu_set_t* saved) {
+    if (pinned) (void)sched_setaffinity(0, sizeof *saved, saved);
+}
+#define PIN_PLAN() PinPlan pin_plan_; pin_plan(&pin_plan_)
+#define PIN_ENTER() cpu_set_t pin_saved_; const int pinned_ = pin_enter(&pin_plan_, &pin_saved_)
+#define PIN_LEAVE() pin_leave(pinned_, &pin_saved_)
+#else
+#define PIN_PLAN() do {} while (0)
+#define PIN_ENTER() do {} while (0)
+#define PIN_LEAVE() do {} while (0)
+#endif
+
+/* Same, over an explicit list of pixel indices (bench.py samples whole rows of a large image).  The running mean of a pixel
+ * is kept in registers over its passes and written once (the same recurrence in the same order: bit-identical), so threads
+ * working on neighbouring pixels do not trade cache lines of `res` pass by pass. */
 int port_render_gids(const OracleScene* s, const int32_t* seeds, int n_passes, int first_spp, const int32_t* gids,
                      int64_t n_gids, float* res, int threads) {
     Sun sun = sun_new(s->sun);
     if (threads < 1) threads = 1;
+    PIN_PLAN();
 #pragma omp parallel num_threads(threads)
     {
         Counters local;
         memset(&local, 0, sizeof local);
         t_ctr = g_count_enabled ? &local : 0;
+        PIN_ENTER();
 #pragma omp for schedule(dynamic, 64)
         for (int64_t i = 0; i < n_gids; i++) {
             int gid = gids[i];
             float* px = res + 3 * (int64_t)gid;
+            float m0 = px[0], m1 = px[1], m2 = px[2];
             for (int k = 0; k < n_passes; k++) {
                 int spp = first_spp + k;
                 v3 c = ext_active() ? trace_sample_ext(s, &sun, &g_ext, seeds[k], gid) : trace_sample(s, &sun, seeds[k], gid, 0, 0);
-                px[0] = (px[0] * spp + c.x) / (spp + 1);
-                px[1] = (px[1] * spp + c.y) / (spp + 1);
-                px[2] = (px[2] * spp + c.z) / (spp + 1);
+                m0 = (m0 * spp + c.x) / (spp + 1);
+                m1 = (m1 * spp + c.y) / (spp + 1);
+                m2 = (m2 * spp + c.z) / (spp + 1);
             }
+            px[0] = m0;
+            px[1] = m1;
+            px[2] = m2;
         }
+        PIN_LEAVE();
         if (g_count_enabled) counters_merge(&local);
         t_ctr = 0;
     }

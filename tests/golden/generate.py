@@ -87,7 +87,6 @@ def write_helpers(ref):
     np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
 
 
-LIBM_SCENES = ("outdoor", "indoor_sun", "entities")
 LIBM_SPP = 32
 
 
@@ -95,17 +94,32 @@ def write_libm():
     """libm_platform.npz: the SAME reference object linked against a SECOND conforming platform layer — glibc libm and unfused
     dot / cross / normalize instead of rt_math.h (`make -C oracle ref_libm`) — renders three golden scenes at LIBM_SPP passes.
     Two conforming platforms differ in last bits, so these images are compared statistically (tests/test_platform_layer.py):
-    a guard that does not share rt_math.h with what it checks."""
+    a guard that does not share rt_math.h with what it checks.  The same file is the fixture of the BIT-EXACT pin of the
+    restatement's logic: oracle/port.c built with -DPORT_LIBM (the same second platform layer) must reproduce every image, preview
+    and timed row in it (all ten golden scenes, and the BASELINE views at the sizes that are timed: `timed_<view>_res`)."""
     import subprocess
     subprocess.run(["make", "-C", os.path.join(os.path.dirname(HERE), "..", "oracle"), "ref_libm"], check=True, stdout=subprocess.DEVNULL)
     libm = binding.RefLib(os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "libchunky_ref_libm.so"))
     seeds = scenes.java_random_ints(LIBM_SPP)
     out = {"seeds": seeds}
-    for name in LIBM_SCENES:
+    for name in gs.NAMES:
         sc = gs.make(name)
         out[name + "_digest"] = gs.input_digest(sc)
         out[name + "_res"] = libm.render_passes(binding.SceneHandle(sc), seeds)
+        out[name + "_preview"] = libm.preview(binding.SceneHandle(sc))
         print("libm", name, float(out[name + "_res"].mean()), flush=True)
+    tseeds = scenes.java_random_ints(gs.TIMED_PASSES)
+    for name in gs.TIMED_VIEWS:
+        sc = gs.timed_view(name)
+        h = binding.SceneHandle(sc)
+        rows = gs.timed_rows(sc)
+        res = np.zeros((len(rows), sc.width, 3), np.float32)
+        for k, y in enumerate(rows):
+            full = libm.render_passes(h, tseeds, gid_range=(y * sc.width, (y + 1) * sc.width), threads=8)
+            res[k] = full.reshape(-1, 3)[y * sc.width:(y + 1) * sc.width]
+        out["timed_" + name + "_digest"] = gs.input_digest(sc)
+        out["timed_" + name + "_res"] = res
+        print("libm timed", name, float(res.mean()), flush=True)
     np.savez_compressed(os.path.join(HERE, "libm_platform.npz"), **out)
 
 

@@ -108,7 +108,7 @@ def test_outdoor_block_shards(gpu_instance, port, outdoor, world, rank, passes):
     """The split bench.py --gpus N uses (chunky_render_set_shard with tile 0): the image's 16 x 16 blocks dealt round-robin,
     rendered by the pool kernel in the same tile shape as the whole image.  The rank's pixels of whole image rows (the half-
     padded bottom block row of 1080 lines included) against the oracle, everybody else's stay zero, and the ranks' pixel
-    sets partition the image; the grouped kernel refuses the mode."""
+    sets partition the image; the grouped kernel (which has no block mapping) renders the same share from a pixel list."""
     sc = outdoor
     n = sc.width * sc.height
     seeds = native.java_random_ints(passes)
@@ -128,8 +128,11 @@ def test_outdoor_block_shards(gpu_instance, port, outdoor, world, rank, passes):
     assert not img[mask].any()                     # every pixel of the other ranks stays zero (the reduce adds them)
     assert np.count_nonzero(img[own].any(axis=1)) > 0.9 * own.size
     r.set_option(native.OPT_KERNEL, 8)
-    with pytest.raises(Exception):
-        r.render_passes(seeds[:2])
+    r.reset()
+    r.render_passes(seeds[:2])
+    assert r.kernel_info()["pool"] < 0
+    compare_rows(r, port, sc, seeds[:2], mine, f"outdoor block share {rank}/{world}, round 1's kernel")
+    assert not r.read().reshape(-1, 3)[mask].any()
     r.close()
     loader.close()
 
