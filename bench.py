@@ -1,36 +1,47 @@
 #!/usr/bin/env python3
-"""bench.py — Msamples/s of the path-tracing hot path on BASELINE.json's headline workload.
+"""bench.py — Msamples/s of the path-tracing hot path on BASELINE.json's workloads.
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: starts one child process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --config {1,2,3,4}                     (default 2: the headline, the line the driver records)
+    python bench.py --group N                              (one process, N GPUs behind one context: what a Chunky JVM binds)
 
-Workload (config.workload): BASELINE.json configs[2] — the synthetic 32x32-chunk outdoor world at
-1920x1080, draw-depth 256, sun + sky, seeds from java.util.Random(0) — because that is the scene
-the metric is quoted on and it fits one GPU.  A "step" is `--passes` passes (samples per pixel)
-over the whole image, one launch (default 256, the most a launch carries, so the default 4 steps are
-the 1024 spp BASELINE.json quotes the configuration at; every launch ends with a ~0.75 ms tail in which
-the longest paths of its last samples finish, so fewer, longer launches waste less — 1 % at N = 1, 7 %
-of an eighth share); scene upload is outside the timed region, the framebuffer lives in HBM.
+Workloads (`--config`, named in config.workload):
+  2  BASELINE configs[2] — the synthetic 32x32-chunk outdoor world at 1920x1080, draw-depth 256, sun + sky, seeds from
+     java.util.Random(0): the scene the metric is quoted on.  A step is 256 passes (one launch, the most a launch carries);
+     the default 4 steps are the 1024 spp the configuration is quoted at.
+  1  configs[1] — the reference's benchmark/OpenCL_test city (tests/golden fixture), 1920x1080, 64 passes per step (4 = its 256 spp).
+  3  configs[3] — the indoor emitter room, sun flag 0, 1920x1080, 256 passes per step (the reference's light transport).
+  4  configs[4] — 32x32-chunk world + 100 000 world / 5 000 actor triangles at its stated 3840x2160, 16 passes per step.
+Scene upload is outside the timed region; the framebuffer lives in HBM.
 
-N > 1: one process per GPU, the scene replicated, the image cut into 16x16-pixel blocks dealt
-round-robin (chunky_render_set_shard), no collective on the data path, ONE RCCL reduce of the
-per-rank framebuffers to rank 0 inside the timed region (the read-back).  Total work is fixed as
-N grows => "scaling": "strong".
+The timed region follows the reference's loop (OpenClPathTracingRenderer.java:95-184): passes accumulate as a float running
+mean; every 1024 spp (its merge interval) the buffer is read back and the mean starts again from zero.  At N = 1 the
+read-back itself is NOT in `value` (inputs and outputs stay in HBM, as the contract says) — `end_to_end` below times it.
+N > 1: one process per GPU, the scene replicated, the image cut into 16x16-pixel blocks dealt round-robin
+(chunky_render_set_shard), no collective on the data path, ONE RCCL reduce of the per-rank framebuffers to rank 0 per
+read-back (every 1024 spp and at the end), inside the timed region.  Total work is fixed as N grows => "scaling": "strong".
 
 The JSON line also carries:
   roofline     — the contract figure: achieved = ALGORITHMIC bytes per sample of the reference's
                  access stream (counted by the CPU oracle on a row-sample of this same view) x samples per launch /
                  mean launch duration from HIP events on the launch stream, against the 8 TB/s HBM peak.  It is a
-                 work-rate convention: the scene is cache-resident, so physical HBM traffic is ~1 % of it.  `traffic`
-                 (PMC FETCH_SIZE x2 + WRITE_SIZE per launch) and `valu` (VALU issue share and lane utilisation — the
-                 real limiter) come from the committed PMC summary named in `pmc_source` and are attached only when
-                 that summary was collected for the kernel / launch shape of this run; otherwise they are null.
-                 `limits` (same source, same condition) is the steering metric: valu_lane_frac = VALU issue share x lane
-                 utilisation, the L1's tag look-ups per cycle, L2 request bandwidth against its peak, the wait share, and the
-                 limiter they add up to — `frac` itself is saturated by the cache-resident scene and ranks nothing.
-  per_rank     — N > 1: every rank's kernel milliseconds (HIP events) and the milliseconds of the read-back reduce.
-  cpu_baseline — the C restatement of the reference kernel (oracle/port.c, kind "port") timed on
-                 this box's host cores on a bounded row-sample of the same workload (rank 0, N=1).
+                 work-rate convention: the scene is cache-resident, so physical HBM traffic is a few % of it.  `traffic`
+                 (PMC FETCH_SIZE x2 + WRITE_SIZE per launch), `valu` and `limits` (VALU lane fraction, L1 tag look-ups per
+                 cycle, L2 request bandwidth, wait share: the real limiter) come from the committed PMC summary named in
+                 `pmc_source` and are attached only when it was collected for the kernel / launch shape of this run.
+  end_to_end   — N = 1 (and --group): the same spp through chunky_render_run_ex with merge interval 1024 — the reference's
+                 whole loop incl. the climb to full-size launches, every read-back into host memory and the double-precision
+                 merge into Chunky's sample buffer — cold (first run on a fresh target) and warm (second run).
+  image_check  — after the timed region every rank renders 4 passes of the same view, the read-back collective runs once
+                 more, and rank 0 compares whole image rows with tests/golden/timed_rows.npz (rendered by the REFERENCE
+                 build): the first multi-GPU run says by itself whether the reduced image is the reference's.
+  group_check  — N > 1: rank 0 alone then opens ALL N GPUs behind one context (chunky_group_create, the in-process path a
+                 JVM binds), renders one step, and reports per-member peer-access status, kernel and gather milliseconds
+                 and the same image check; a failure is reported in the line, it does not fail the bench.
+  per_rank     — N > 1: every rank's kernel milliseconds (HIP events) and the milliseconds of its read-back reduces.
+  cpu_baseline — the C restatement of the reference kernel (oracle/port.c, kind "port") timed on this box's host cores
+                 (workers pinned one per CPU) on a bounded sample of the same view (rank 0, N = 1).
 """
 import argparse
 import json
@@ -44,6 +55,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+MERGE_INTERVAL = 1024  # OpenClPathTracingRenderer.java:158
+
+
+def workload(config: int, args):
+    """(scene, passes per step, name of its rows in tests/golden/timed_rows.npz, description, spp of the end-to-end leg)."""
+    from chunkyclplugin_amd import scenes
+    if config == 1:
+        from chunkyclplugin_amd import octree2
+        sc = octree2.cached_benchmark_scene(1920, 1080)
+        return sc, 64, "city", "BASELINE configs[1]: the reference's benchmark/OpenCL_test city (flat-colour cubes), saved camera", 256
+    if config == 3:
+        sc = scenes.indoor_room(size=64, width=1920, img_height=1080)
+        return sc, 256, "indoor", "BASELINE configs[3]: indoor emitter room (64^3), sun flag 0, the reference's light transport", 1024
+    if config == 4:
+        base = scenes.cached_outdoor_world(chunks=32, height=256)
+        sc = scenes.add_entities(base, 100000, seed=11, actor_tris=5000, region=((40, 90, 40), (470, 170, 470))).with_view(3840, 2160)
+        return sc, 16, "entities4k", "BASELINE configs[4]: 32x32-chunk world + 100 000 world / 5 000 actor triangles (entity BVHs)", 64
+    sc = scenes.cached_outdoor_world(chunks=args.chunks, height=256, width=args.width, img_height=args.height)
+    golden = "outdoor" if (args.chunks, args.width, args.height) == (32, 1920, 1080) else None
+    return sc, 256, golden, f"BASELINE configs[2]: synthetic {args.chunks}x{args.chunks}-chunk outdoor world", 1024
 
 
 def sample_rows(height: int, n_rows: int):
@@ -51,8 +82,9 @@ def sample_rows(height: int, n_rows: int):
     return list(range(step // 2, height, step))[:n_rows]
 
 
-def oracle_row_sample(sc, seeds, rows, threads, count: bool):
-    """Run the CPU oracle on whole rows of the 1080p view. Returns (samples, seconds, counters)."""
+def oracle_row_sample(sc, seeds, rows, threads, count: bool, pin: bool = False):
+    """Run the CPU oracle on whole rows of the view. Returns (samples, seconds, counters)."""
+    import ctypes as C
     from oracle import binding
     port = binding.port()
     h = binding.SceneHandle(sc)
@@ -61,11 +93,118 @@ def oracle_row_sample(sc, seeds, rows, threads, count: bool):
     if count:
         port.counters(enable=True, reset=True)
         port.counters(reset=True)
+    port.lib.port_set_pinning.argtypes = [C.c_int]
+    port.lib.port_set_pinning.restype = None
+    port.lib.port_set_pinning(1 if pin else 0)
     t0 = time.perf_counter()
     port.render_gids(h, seeds, gids, res=res, threads=threads)
     dt = time.perf_counter() - t0
+    port.lib.port_set_pinning(0)
     c = port.counters(enable=False, reset=True) if count else None
     return gids.size * len(seeds), dt, c
+
+
+def golden_rows(name):
+    """(seeds, row indices, rows [n, W, 3]) of a timed view in tests/golden/timed_rows.npz, or None."""
+    path = os.path.join(ROOT, "tests", "golden", "timed_rows.npz")
+    if not name or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    if name + "_res" not in g.files:
+        return None
+    return g["seeds"], g[name + "_rows"], g[name + "_res"]
+
+
+def compare_golden(image, gold, width):
+    """image: float32 [3*W*H] (the read-back); gold from golden_rows.  -> the image_check object."""
+    _, rows, want = gold
+    img = image.reshape(-1, width, 3)
+    got = img[np.asarray(rows, np.int64)]
+    same = (np.ascontiguousarray(got).view(np.uint32) == np.ascontiguousarray(want).view(np.uint32)).all(axis=2)
+    with np.errstate(all="ignore"):
+        rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-6)
+    return {"rows": [int(y) for y in rows], "pixels": int(same.size), "pixels_differing": int((~same).sum()),
+            "bit_identical": bool(same.all()), "max_rel_err": float(np.nanmax(rel)) if rel.size else 0.0,
+            "passes": int(len(gold[0])), "against": "tests/golden/timed_rows.npz (rows rendered by the reference build, oracle/_ref)"}
+
+
+def pmc_entry(info, passes_per_launch, samples_per_launch, kernel_variant):
+    """The committed PMC summary collected for exactly this launch shape, or None."""
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tp) or kernel_variant != 0:
+        return None
+    try:
+        pm = json.load(open(tp))
+        for e in pm.get("entries", [pm]):
+            if (e.get("kernel_info") == [info["tree"], info["group"], int(info["bvh"]), info["pool"]] and e.get("passes_per_launch") == passes_per_launch
+                    and e.get("samples_per_launch") == samples_per_launch):
+                return e
+    except Exception:
+        pass
+    return None
+
+
+def end_to_end_leg(loader, sc, spp, make_renderer):
+    """The reference's whole loop through chunky_render_run_ex, merge interval 1024: cold (fresh target) and warm."""
+    r = make_renderer(loader)
+    n = 3 * sc.width * sc.height
+    out = {"spp": spp, "merge_interval": MERGE_INTERVAL}
+    for label in ("cold", "warm"):
+        buf = np.zeros(n, np.float64)
+        merges = []
+        r.kernel_time()
+        t0 = time.perf_counter()
+        got = r.render_ex(buf, 0, spp, merge_interval=MERGE_INTERVAL, merged=merges.append)
+        dt = time.perf_counter() - t0
+        ms, launches = r.kernel_time()
+        assert got == spp
+        out[("cold_" if label == "cold" else "") + "value"] = round(sc.width * sc.height * spp / dt / 1e6, 3)
+        out[label] = {"seconds": round(dt, 5), "launches": launches, "kernel_ms": round(ms, 3), "readbacks": len(merges)}
+        out["readbacks"] = len(merges)
+    out["unit"] = "Msamples/s"
+    out["includes"] = ("launch-size climb (cold), every read-back into host memory, the double-precision merge into the sample "
+                       "buffer (OpenClPathTracingRenderer.java:162-178)")
+    out["finite"] = bool(np.isfinite(buf).all())
+    r.close()
+    return out
+
+
+def group_leg(devices, sc, seeds, passes, gold, kernel_variant):
+    """One process, len(devices) GPUs behind one context (chunky_group_create): one step + the gather, timed on their own."""
+    from chunkyclplugin_amd import native
+    from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance
+    inst = RendererInstance.group(devices)
+    try:
+        loader = HipSceneLoader(inst)
+        loader.load_packed(sc)
+        r = HipPathTracingRenderer(loader, sc.width, sc.height)
+        r.set_camera(sc.projector_type, sc.camera)
+        r.set_option(native.OPT_KERNEL, kernel_variant)
+        r.render_passes(seeds[:passes])  # warm-up at the timed launch shape (staging arrays are allocated here)
+        r.gather()
+        r.reset()
+        r.kernel_time()
+        t0 = time.perf_counter()
+        r.render_passes(seeds[:passes], sync=False)
+        r.sync()
+        t1 = time.perf_counter()
+        r.gather()
+        t2 = time.perf_counter()
+        ms, launches = r.kernel_time()
+        out = {"members": len(devices), "devices": [int(d) for d in devices], "peer_status": inst.peer_status(),
+               "peer_status_legend": "0 local (member 0's device), 1 direct (peer access enabled: xGMI), 2 staged (no peer access), < 0 = -hipError",
+               "passes": passes, "render_ms": round((t1 - t0) * 1e3, 3), "gather_ms": round((t2 - t1) * 1e3, 3),
+               "kernel_ms_slowest_member": round(ms, 3),
+               "value": round(sc.width * sc.height * passes / (t2 - t0) / 1e6, 3), "unit": "Msamples/s"}
+        if gold is not None:
+            r.reset()
+            r.render_passes(gold[0])
+            out["image_check"] = compare_golden(r.read(), gold, sc.width)
+        r.close()
+        loader.close()
+        return out
+    finally:
+        inst.close()
 
 
 def main():
@@ -73,7 +212,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--passes", type=int, default=256, help="passes (spp) per step; one launch carries up to 256")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4), help="BASELINE.json configs[n] (default 2: the headline)")
+    ap.add_argument("--passes", type=int, default=0, help="passes (spp) per step; 0 = the configuration's (256 for the headline: the most a launch carries)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--chunks", type=int, default=32)
@@ -83,6 +223,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the oracle row-sample too: nothing under oracle/ is loaded, built or spawned (profiler runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end_to_end / image_check / group_check legs (profiler runs)")
+    ap.add_argument("--group", type=int, default=0, help="N > 0: ONE process, N GPUs behind one context (chunky_group_create); "
+                                                         "members share GPU 0 when the box has fewer than N")
     ap.add_argument("--dump", default="", help="rank 0 writes the final (reduced) framebuffer to this .npy file")
     ap.add_argument("--emulate-world", type=int, default=0, help="rig: render only rank 0's share of an N-GPU split on one GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rigs")
@@ -104,33 +247,50 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from chunkyclplugin_amd import native, parallel, scenes
+    from chunkyclplugin_amd import native, parallel
     from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance
 
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    on_gpu = args.backend == "nccl"
     if world > 1:
-        if args.backend == "nccl":
+        if on_gpu:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
 
-    sc = scenes.cached_outdoor_world(chunks=args.chunks, height=256, width=args.width, img_height=args.height)
+    sc, passes, golden_name, what, e2e_spp = workload(args.config, args)
+    if args.passes > 0:
+        passes = args.passes
     n_pix = sc.width * sc.height
-    inst = RendererInstance.get(local_rank)
+    gold = golden_rows(golden_name)
+    group_devices = None
+    if args.group > 0:
+        n_dev = RendererInstance.device_count()
+        group_devices = list(range(args.group)) if n_dev >= args.group else [0] * args.group
+        inst = RendererInstance.group(group_devices)
+    else:
+        inst = RendererInstance.get(local_rank)
     loader = HipSceneLoader(inst)
     loader.load_packed(sc)
-    r = HipPathTracingRenderer(loader, sc.width, sc.height)
-    r.set_camera(sc.projector_type, sc.camera)
-    r.set_option(native.OPT_KERNEL, args.kernel)
+
+    def make_renderer(ld):
+        q = HipPathTracingRenderer(ld, sc.width, sc.height)
+        q.set_camera(sc.projector_type, sc.camera)
+        q.set_option(native.OPT_KERNEL, args.kernel)
+        return q
+
+    r = make_renderer(loader)
     r.set_shard(rank, args.emulate_world or world, args.tile)
     fb = torch.zeros(3 * n_pix, dtype=torch.float32, device="cuda")
+    # the read-back lands in a buffer of its own: rank 0's framebuffer must keep holding only rank 0's tiles
+    image = torch.zeros_like(fb) if world > 1 else fb
     torch.cuda.synchronize()  # the fill runs on torch's stream, the passes on the library's: order them (chunky_hip.h)
     r.set_device_buffer(fb.data_ptr())
 
-    total_passes = (args.warmup + args.steps) * args.passes
-    seeds = native.java_random_ints(total_passes)
+    total_passes = (args.warmup + args.steps) * passes
+    seeds = native.java_random_ints(max(total_passes, MERGE_INTERVAL))
 
     def barrier():
         r.sync()
@@ -139,100 +299,133 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    reduce_ms = []
+
+    def read_back():
+        """What the reference does every merge interval (:162-178), as far as the device side goes: N > 1 — the one RCCL reduce
+        of the per-rank framebuffers onto rank 0 (into `image`); a group — the gather onto member 0; N = 1 — nothing, the
+        image is where the boundary leaves it (HBM)."""
+        r.sync()
+        t = time.perf_counter()
+        if world > 1:
+            image.copy_(fb)
+            parallel.reduce_framebuffer(image, dst=0)  # (a gloo rig stages it through the host)
+            torch.cuda.synchronize()
+        elif group_devices:
+            r.gather()
+        reduce_ms.append((time.perf_counter() - t) * 1e3)
+
     if world > 1:  # the read-back collective once, untimed, on a scratch buffer: communicator and channel set-up are not the path
-        parallel.reduce_framebuffer(torch.zeros_like(fb) if args.backend == "nccl" else torch.zeros(16), dst=0)
-    spp = 0
-    for _ in range(args.warmup):
-        r.render_passes(seeds[spp:spp + args.passes], first_buffer_spp=spp, sync=False)
-        spp += args.passes
+        parallel.reduce_framebuffer(torch.zeros_like(fb) if on_gpu else torch.zeros(16), dst=0)
+
+    def run_steps(n_steps, first_seed):
+        """n_steps steps of `passes` passes, read back + restart of the running mean every MERGE_INTERVAL spp and at the end."""
+        spp_in_buffer, used, backs = 0, first_seed, 0
+        for k in range(n_steps):
+            r.render_passes(seeds[used:used + passes], first_buffer_spp=spp_in_buffer, sync=False)
+            used += passes
+            spp_in_buffer += passes
+            last = k == n_steps - 1
+            if spp_in_buffer >= MERGE_INTERVAL or last:
+                read_back()
+                backs += 1
+                if not last:
+                    r.reset()
+                    spp_in_buffer = 0
+        return backs
+
+    if args.warmup:
+        run_steps(args.warmup, 0)
+        r.reset()
     barrier()
     r.kernel_time()  # discard warmup launches
+    reduce_ms.clear()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r.render_passes(seeds[spp:spp + args.passes], first_buffer_spp=spp, sync=False)
-        spp += args.passes
-    r.sync()
-    t_reduce = time.perf_counter()
-    parallel.reduce_framebuffer(fb, dst=0)  # the read-back collective (one RCCL reduce; no-op at N=1)
-    torch.cuda.synchronize()
-    reduce_ms = (time.perf_counter() - t_reduce) * 1e3
+    readbacks = run_steps(args.steps, args.warmup * passes)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kernel_ms, launches = r.kernel_time()
     info = r.kernel_info()
+    my_reduce_ms = list(reduce_ms)
     per_rank = None
     devices_seen = [local_rank]
     if world > 1:
         objs = [None] * world
-        dist.all_gather_object(objs, (local_rank, torch.cuda.get_device_name(local_rank)))
+        dist.all_gather_object(objs, (local_rank, torch.cuda.get_device_name(local_rank), kernel_ms, my_reduce_ms))
         devices_seen = [o[0] for o in objs]
-    if world > 1:
-        mine = torch.tensor([kernel_ms, reduce_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        per_rank = {"kernel_ms": [round(float(g[0]), 3) for g in gathered], "reduce_ms": [round(float(g[1]), 3) for g in gathered],
-                    "note": "kernel_ms = sum of this rank's launches in the timed region (HIP events); reduce_ms = host time of "
-                            "the one read-back reduce incl. waiting for the slowest rank"}
+        per_rank = {"kernel_ms": [round(float(o[2]), 3) for o in objs], "reduce_ms": [[round(x, 3) for x in o[3]] for o in objs],
+                    "device_names": sorted(set(o[1] for o in objs)),
+                    "note": "kernel_ms = sum of this rank's launches in the timed region (HIP events); reduce_ms = host time of each "
+                            "read-back (copy + RCCL reduce) incl. waiting for the slowest rank"}
     if rank == 0 and args.dump:
-        np.save(args.dump, fb.cpu().numpy())
+        np.save(args.dump, (r.read() if group_devices else image.cpu().numpy()))
+
+    # ---- image check: 4 passes of the same view through the same shards and the same collective, against the reference's rows ----
+    image_check = None
+    if gold is not None and not args.no_extras and not args.emulate_world:
+        r.reset()
+        r.render_passes(gold[0], sync=False)
+        read_back()
+        if rank == 0:
+            image_check = compare_golden(r.read() if group_devices else image.cpu().numpy(), gold, sc.width)
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         local_slots = int(parallel.owned_gids(n_pix, 0, args.emulate_world or world, args.tile, sc.width).size)  # pixels rank 0 renders
         # an emulated share renders only rank 0's tiles: count what was rendered, and say so
-        samples = (min(local_slots, n_pix) if args.emulate_world else n_pix) * args.steps * args.passes
+        samples = (min(local_slots, n_pix) if args.emulate_world else n_pix) * args.steps * passes
         value = samples / dt / 1e6
         # ---- roofline: algorithmic bytes of the reference access stream on this view ---------------
         threads = os.cpu_count() or 1
         # what a launch really carried: chunky_render_passes cuts a step into launches of at most info["passes_per_launch"]
         # passes (256 unless the staged samples would not fit); the timed region's samples over its launches is exact either way
         launch_ms = kernel_ms / max(launches, 1)
-        samples_per_launch = min(local_slots, n_pix) * args.steps * args.passes // max(launches, 1)
-        passes_per_launch = min(args.passes, info["passes_per_launch"])
-        bytes_per_sample, n_s, rows = None, 0, []
+        share = n_pix if group_devices else min(local_slots, n_pix)  # (a group reports its slowest member's kernels for the whole image)
+        samples_per_launch = share * args.steps * passes // max(launches, 1)
+        passes_per_launch = min(passes, info["passes_per_launch"])
+        bytes_per_sample, n_s, rows, cal = None, 0, [], None
         if not args.no_roofline:
             from oracle import binding
             binding.port(build=not args.no_cpu)  # --no-cpu runs (profiler passes) never spawn a compiler
             rows = sample_rows(sc.height, 36)
-            n_s, _, ctr = oracle_row_sample(sc, seeds[:1], rows, threads, count=True)
+            n_s, cal_dt, ctr = oracle_row_sample(sc, seeds[:1], rows, threads, count=True, pin=True)
             bytes_per_sample = binding.algorithmic_bytes(ctr)
+            cal = n_s / max(cal_dt, 1e-6)
         achieved = bytes_per_sample * samples_per_launch / (launch_ms * 1e-3) / 1e9 if (launch_ms > 0 and bytes_per_sample) else 0.0
-        kernel_name = ("render_pool<%d,%d>+fold_kernel" % (info["tree"], info["pool"]) if info["pool"] >= 0 else
+        bvh_tag = ",bvh" if info["bvh"] else ""
+        kernel_name = ("render_pool<%d,%d%s>+fold_kernel" % (info["tree"], info["pool"], bvh_tag) if info["pool"] >= 0 else
                        "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh"))
-        traffic, valu, pmc_source, limits = None, None, None, None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            try:
-                pm = json.load(open(tp))
-                # only for the launch shape the counters were collected on
-                if (pm.get("kernel_info") == [info["tree"], info["group"], int(info["bvh"]), info["pool"]] and pm.get("passes_per_launch") == passes_per_launch
-                        and pm.get("samples_per_launch") == samples_per_launch and args.kernel == 0):
-                    traffic = pm.get("hbm_bytes_per_launch")
-                    valu = pm.get("valu")
-                    limits = pm.get("limits")
-                    pmc_source = pm.get("source")
-            except Exception:
-                traffic = None
+        pm = pmc_entry(info, passes_per_launch, samples_per_launch, args.kernel) if not group_devices else None
+        traffic = pm.get("hbm_bytes_per_launch") if pm else None
+        how = (f"{len(group_devices)} GPU(s) behind one context in one process (chunky_group_create), 16x16-pixel blocks round-robin, one gather per read-back"
+               if group_devices else
+               f"image tiles ({'16x16-pixel blocks' if args.tile == 0 else f'runs of {args.tile} px'}) round-robin over {world} GPU(s), scene replicated, "
+               f"one RCCL reduce per read-back")
         out = {
-            "metric": "Msamples/s, 32x32-chunk scene @1920x1080", "value": round(value, 3), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "metric": "Msamples/s, 32x32-chunk scene @1920x1080" if args.config == 2 else f"Msamples/s, BASELINE configs[{args.config}] @{sc.width}x{sc.height}",
+            "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": len(group_devices) if group_devices else world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: synthetic {args.chunks}x{args.chunks}-chunk outdoor world, "
-                                   f"{sc.width}x{sc.height}, draw-depth 256, sun+sky, {args.passes} spp per step",
-                       "passes_per_step": args.passes, "spp_timed": args.steps * args.passes,
+            "config": {"workload": f"{what}, {sc.width}x{sc.height}, draw-depth 256, {passes} spp per step",
+                       "baseline_config": args.config, "passes_per_step": passes, "spp_timed": args.steps * passes,
+                       "readbacks_timed": readbacks, "merge_interval": MERGE_INTERVAL,
                        "octree_ints": int(sc.octree.size), "octree_depth": int(sc.octree_depth),
-                       "parallelism": f"image tiles ({'16x16-pixel blocks' if args.tile == 0 else f'runs of {args.tile} px'}) round-robin over {world} GPU(s), scene replicated, "
-                                      f"one RCCL reduce per read-back", "kernel_variant": args.kernel},
+                       "entity_bvh_ints": int(len(sc.world_bvh) + len(sc.actor_bvh)),
+                       "parallelism": how, "kernel_variant": args.kernel},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "achieved_is": "algorithmic bytes of the reference access stream / launch time (SURVEY 8d), "
                                         "not physical HBM traffic: the scene is cache-resident",
                          "physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and launch_ms > 0 else None,
-                         "valu": valu, "limits": limits, "pmc_source": pmc_source,
+                         "valu": pm.get("valu") if pm else None, "limits": pm.get("limits") if pm else None,
+                         "pmc_source": pm.get("source") if pm else None,
                          "algorithmic_bytes_per_sample": round(bytes_per_sample, 1) if bytes_per_sample else None,
                          "kernel": kernel_name, "launches": launches, "launch_ms": round(launch_ms, 4),
                          "samples_per_launch": samples_per_launch,
@@ -241,34 +434,61 @@ def main():
         if args.emulate_world:
             out["emulated_world"] = args.emulate_world
             out["metric"] += f" — EMULATED rank-0 share of a {args.emulate_world}-GPU split on one GPU (not a multi-GPU result)"
-        # what the collective actually ran on: the backend and world size torch.distributed reports ("nccl" IS RCCL on ROCm)
-        out["rccl_ranks"] = dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)
+        # what the collective actually ran on: the backend and world size torch.distributed reports ("nccl" IS RCCL on ROCm);
+        # a single process runs no communicator at all
+        out["rccl_ranks"] = dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0
         out["collective"] = {"backend": dist.get_backend() if world > 1 else None, "ranks": dist.get_world_size() if world > 1 else 1,
-                             "devices": sorted(set(devices_seen)),
+                             "devices": sorted(set(devices_seen)) if not group_devices else group_devices,
+                             "readback_ms": [round(x, 3) for x in my_reduce_ms],
                              "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                          ("bench.py self-spawn" if "RANK" in os.environ else "none")}
+        if group_devices:
+            out["group"] = {"members": len(group_devices), "devices": group_devices, "peer_status": inst.peer_status(),
+                            "peer_status_legend": "0 local (member 0's device), 1 direct (peer access enabled: xGMI), 2 staged (no peer access), < 0 = -hipError",
+                            "gather_ms": [round(x, 3) for x in my_reduce_ms]}
         if per_rank:
             out["per_rank"] = per_rank
-        if world == 1 and not args.no_cpu and not args.no_roofline:
-            # bounded CPU leg: the SAME full-resolution view, whole image, P passes with P sized from a
-            # calibration run so the leg costs about --cpu-seconds of wall time on all host cores
-            all_rows = sample_rows(sc.height, sc.height)
-            p_cpu, done, spent = 2, 0, 0.0
-            for _ in range(3):  # grow the pass count until the leg costs about --cpu-seconds
-                done, spent, _c = oracle_row_sample(sc, seeds[:p_cpu], all_rows, threads, count=False)
-                if spent >= 0.7 * args.cpu_seconds or p_cpu >= 64:
-                    break
-                p_cpu = int(min(64, max(p_cpu + 1, round(p_cpu * args.cpu_seconds / max(spent, 1e-3)))))
-            out["cpu_baseline"] = {"value": round(done / spent / 1e6, 4), "unit": "Msamples/s", "cores": threads,
-                                   "kind": "port",
-                                   "sample": f"{done} samples = the same {sc.width}x{sc.height} view, {p_cpu} pass(es), "
+        if image_check is not None:
+            out["image_check"] = image_check
+
+    # ---- N > 1: rank 0 alone opens all GPUs behind one context — the in-process path a JVM binds (the others wait) ----------
+    if world > 1 and on_gpu and not args.one_device and not args.no_extras:
+        if rank == 0:
+            try:
+                out["group_check"] = group_leg(sorted(set(devices_seen)), sc, seeds, passes, gold, args.kernel)
+            except Exception as e:  # first contact with real multi-GPU hardware: report, do not fail the bench
+                out["group_check"] = {"error": f"{type(e).__name__}: {e}"}
+        dist.barrier()
+
+    if rank == 0:
+        if world == 1 and not args.no_extras and not args.emulate_world:
+            try:
+                out["end_to_end"] = end_to_end_leg(loader, sc, e2e_spp, make_renderer)
+            except Exception as e:
+                out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_cpu and not args.no_roofline and cal:
+            # bounded CPU leg on the SAME view: whole image x P passes when the budget allows, else evenly spread whole rows x 1
+            # pass — sized from the rate of the counting run so the leg costs about --cpu-seconds on all host cores
+            target = cal * args.cpu_seconds
+            if target >= n_pix:
+                p_cpu, leg_rows = int(min(64, max(1, target // n_pix))), sample_rows(sc.height, sc.height)
+            else:
+                p_cpu, leg_rows = 1, sample_rows(sc.height, int(max(36, min(sc.height, target // sc.width))))
+            done, spent, _c = oracle_row_sample(sc, seeds[:p_cpu], leg_rows, threads, count=False, pin=True)
+            cpu_v = done / spent / 1e6
+            out["cpu_baseline"] = {"value": round(cpu_v, 4), "unit": "Msamples/s", "cores": threads, "per_thread": round(cpu_v / threads, 5),
+                                   "kind": "port", "pinned": True,
+                                   "sample": f"{done} samples = {len(leg_rows)} whole rows of the same {sc.width}x{sc.height} view, {p_cpu} pass(es), "
                                              f"{spent:.1f} s of oracle/port.c (C restatement of the reference kernel) "
-                                             f"with OpenMP on all {threads} host cores"}
-            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+                                             f"with OpenMP on all {threads} host threads, one worker pinned per CPU",
+                                   "scaling": "profiles/r04_cpu_sweep.jsonl (1 / 8 / 64 / 128 / 256 threads on this box type)"}
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
 
     r.close()
     loader.close()
+    if group_devices:
+        inst.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -1037,9 +1037,11 @@ int port_render_passes(const OracleScene* s, const int32_t* seeds, int n_passes,
             Counters local;
             memset(&local, 0, sizeof local);
             t_ctr = g_count_enabled ? &local : 0;
+            const Sun my_sun = sun;  /* per-worker copies: see port_render_gids */
+            const OracleScene my_scene = *s;
 #pragma omp for schedule(dynamic, 256)
             for (int64_t gid = gid_begin; gid < gid_end; gid++) {
-                v3 c = ext_active() ? trace_sample_ext(s, &sun, &g_ext, seed, (int)gid) : trace_sample(s, &sun, seed, (int)gid, 0, 0);
+                v3 c = ext_active() ? trace_sample_ext(&my_scene, &my_sun, &g_ext, seed, (int)gid) : trace_sample(&my_scene, &my_sun, seed, (int)gid, 0, 0);
                 float* px = res + 3 * gid;
                 px[0] = (px[0] * spp + c.x) / (spp + 1);
                 px[1] = (px[1] * spp + c.y) / (spp + 1);
@@ -1102,6 +1104,11 @@ int port_render_gids(const OracleScene* s, const int32_t* seeds, int n_passes, i
         memset(&local, 0, sizeof local);
         t_ctr = g_count_enabled ? &local : 0;
         PIN_ENTER();
+        /* every worker reads its OWN copies of what the samples read all the time: `sun` and `*s` live in the calling thread's
+         * stack frame / the caller's memory, next to words that thread keeps writing while it works — on a 2-socket, 16-CCD
+         * host that one shared line capped the whole leg at ~14 Msamples/s whatever the thread count (profiles/r04_cpu_sweep) */
+        const Sun my_sun = sun;
+        const OracleScene my_scene = *s;
 #pragma omp for schedule(dynamic, 64)
         for (int64_t i = 0; i < n_gids; i++) {
             int gid = gids[i];
@@ -1109,7 +1116,7 @@ int port_render_gids(const OracleScene* s, const int32_t* seeds, int n_passes, i
             float m0 = px[0], m1 = px[1], m2 = px[2];
             for (int k = 0; k < n_passes; k++) {
                 int spp = first_spp + k;
-                v3 c = ext_active() ? trace_sample_ext(s, &sun, &g_ext, seeds[k], gid) : trace_sample(s, &sun, seeds[k], gid, 0, 0);
+                v3 c = ext_active() ? trace_sample_ext(&my_scene, &my_sun, &g_ext, seeds[k], gid) : trace_sample(&my_scene, &my_sun, seeds[k], gid, 0, 0);
                 m0 = (m0 * spp + c.x) / (spp + 1);
                 m1 = (m1 * spp + c.y) / (spp + 1);
                 m2 = (m2 * spp + c.z) / (spp + 1);

@@ -30,12 +30,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_bench(world, dump, extra=(), launcher=True):
+def _run_bench(world, dump, extra=(), launcher=True, steps=1, passes=PASSES, small=True):
     launch = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] if launcher else [sys.executable])
-    cmd = [*launch, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
-           "--passes", str(PASSES), "--width", str(W), "--height", str(H), "--chunks", str(CHUNKS), "--one-device", "--backend", "gloo",
-           "--no-cpu", "--dump", dump, *extra]
+    size = ["--passes", str(passes), "--width", str(W), "--height", str(H), "--chunks", str(CHUNKS)] if small else []
+    cmd = [*launch, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "0",
+           *size, "--one-device", "--backend", "gloo", "--no-cpu", "--dump", dump, *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -80,7 +80,9 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path, single_rank_ima
     _sc, want = single_rank_image
     dump = str(tmp_path / "fb_self.npy")
     line = _run_bench(2, dump, launcher=False)
-    assert line["n_gpus"] == 2 and line["collective"] == {"backend": "gloo", "ranks": 2, "devices": [0], "launcher": "bench.py self-spawn"}
+    coll = dict(line["collective"])
+    assert len(coll.pop("readback_ms")) == 1
+    assert line["n_gpus"] == 2 and coll == {"backend": "gloo", "ranks": 2, "devices": [0], "launcher": "bench.py self-spawn"}
     assert line["rccl_ranks"] == 0  # gloo rig: no RCCL ranks claimed
     np.testing.assert_array_equal(np.load(dump).view(np.uint32), want.view(np.uint32))
 
@@ -90,5 +92,64 @@ def test_single_rank_through_the_spawn_path(tmp_path, single_rank_image):
     _sc, want = single_rank_image
     dump = str(tmp_path / "fb_one.npy")
     line = _run_bench(1, dump, extra=("--spawn",), launcher=False)
-    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["collective"]["launcher"] == "bench.py self-spawn"
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 0 and line["collective"]["launcher"] == "bench.py self-spawn"  # one process: no communicator
     np.testing.assert_array_equal(np.load(dump).view(np.uint32), want.view(np.uint32))
+
+
+def test_read_back_every_merge_interval(tmp_path, gpu_instance):
+    """The reference reads the buffer back every 1024 spp and starts the running mean again (OpenClPathTracingRenderer.java:158-178):
+    three steps of 600 passes on two ranks cross the interval once — two read-back reduces in the timed region, and the final
+    image is the mean of the passes after the restart only (seeds 1200..1799 from spp 0)."""
+    dump = str(tmp_path / "fb_interval.npy")
+    line = _run_bench(2, dump, steps=3, passes=600)
+    assert line["config"]["readbacks_timed"] == 2 and line["config"]["spp_timed"] == 1800
+    assert [len(x) for x in line["per_rank"]["reduce_ms"]] == [2, 2]
+    sc = scenes.cached_outdoor_world(chunks=CHUNKS, height=256, width=W, img_height=H)
+    loader = HipSceneLoader(gpu_instance)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, W, H)
+    r.set_camera(sc.projector_type, sc.camera)
+    r.render_passes(native.java_random_ints(1800)[1200:])
+    np.testing.assert_array_equal(np.load(dump).view(np.uint32), r.read().view(np.uint32))
+    r.close()
+    loader.close()
+
+
+def test_headline_line_checks_its_own_image(tmp_path):
+    """The driver's run, shortened: the headline workload at full size on two ranks (sharing the one GPU), one step.  After the
+    timed region bench.py renders 4 passes through the same shards and the same collective and compares whole rows with the
+    reference build's (tests/golden/timed_rows.npz): the line carries the verdict."""
+    line = _run_bench(2, str(tmp_path / "fb_full.npy"), small=False)
+    assert line["config"]["baseline_config"] == 2 and line["config"]["passes_per_step"] == 256
+    chk = line["image_check"]
+    assert chk["bit_identical"] and chk["pixels"] == 4 * 1920 and chk["pixels_differing"] == 0, chk
+
+
+def _run_single(args):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", *args],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_group_mode_of_the_bench():
+    """`bench.py --group 2`: ONE process, two members behind one context (both on GPU 0 here) — what a JVM binds.  The line
+    reports each member's peer-access status and the gather milliseconds, checks its image against the reference's rows, and
+    runs the reference's whole loop (end_to_end) on the group."""
+    line = _run_single(["--group", "2"])
+    assert line["n_gpus"] == 2 and line["group"]["peer_status"] == [0, 0] and len(line["group"]["gather_ms"]) == 1
+    assert line["image_check"]["bit_identical"], line["image_check"]
+    e = line["end_to_end"]
+    assert e["readbacks"] == 1 and e["value"] > 0 and e["cold_value"] > 0 and e["finite"], e
+
+
+@pytest.mark.parametrize("config,kernel", [(1, "render_pool<18,56>+fold_kernel"), (3, "render_pool<17,56>+fold_kernel"), (4, "render_pool<17,16,bvh>+fold_kernel")])
+def test_other_baseline_configs_through_the_bench(config, kernel):
+    """`bench.py --config n`: the other BASELINE configurations with the same JSON schema, each checking its own image."""
+    line = _run_single(["--config", str(config)])
+    assert line["config"]["baseline_config"] == config and line["roofline"]["kernel"] == kernel, line["roofline"]
+    assert line["image_check"]["bit_identical"], line["image_check"]
+    assert line["end_to_end"]["value"] > 0 and line["roofline"]["frac"] > 0 and line["value"] > 0

@@ -31,7 +31,7 @@ for g in ${PMC_GROUPS:-sq1 sq2 tcc tcp fetch write}; do
   if [ -n "${PMC_SCRIPT:-}" ]; then
     (cd $R && timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc ${G[$g]} --output-format csv -d $OUT/$g -- python3 $PMC_SCRIPT > $OUT/$g.log 2>&1) || echo "group $g failed"
   else
-    timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc ${G[$g]} --output-format csv -d $OUT/$g -- python3 $R/bench.py --no-cpu --no-roofline --steps 2 --warmup 1 "$@" > $OUT/$g.log 2>&1 || echo "group $g failed"
+    timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc ${G[$g]} --output-format csv -d $OUT/$g -- python3 $R/bench.py --no-cpu --no-roofline --no-extras --steps 2 --warmup 1 "$@" > $OUT/$g.log 2>&1 || echo "group $g failed"
   fi
 done
 python3 $R/tools/pmc_summary.py $OUT ${PMC_KERNEL:-render} > $OUT/summary.json
