@@ -11,6 +11,10 @@
 #include "path_state.hpp"
 #include "pool_walk.hpp"
 
+#ifndef CHUNKY_STAGING_STORE
+#define CHUNKY_STAGING_STORE 0  // how finished samples reach the staging array: 0 = non-temporal (measured best), 1-3: see the deposit site
+#endif
+
 namespace chunky {
 
 // SHADE of the EXTENDED integrator: oracle/port.c trace_sample_ext, operation for operation, as a
@@ -553,9 +557,21 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             if (st == ST_NEXT) {  // the path is finished: its radiance waits in the staging array for fold_kernel
                 // streamed past the caches (nt): written once, read once by fold_kernel; the L2 stays with the tree
                 float* __restrict__ out = A->staging + 3 * (size_t)(unsigned)L.sidx;
-                __builtin_nontemporal_store(L.radiance.x, out);   // (plain stores, merged by the L2: -2.3 % on the bench)
+#if CHUNKY_STAGING_STORE == 1  // tuning builds (tools/variants.sh): plain stores, merged by the L2 (-2.3 % on the bench)
+                out[0] = L.radiance.x, out[1] = L.radiance.y, out[2] = L.radiance.z;
+#elif CHUNKY_STAGING_STORE == 2  // device-scope stores (sc1): written through the L2
+                __hip_atomic_store(out, L.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(out + 1, L.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(out + 2, L.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif CHUNKY_STAGING_STORE == 3  // system-scope stores (sc0 sc1)
+                __hip_atomic_store(out, L.radiance.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(out + 1, L.radiance.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(out + 2, L.radiance.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+                __builtin_nontemporal_store(L.radiance.x, out);
                 __builtin_nontemporal_store(L.radiance.y, out + 1);
                 __builtin_nontemporal_store(L.radiance.z, out + 2);
+#endif
                 st = ST_FRESH;
             }
             part_end<STATS>(&parts, PT_DEPOSIT);

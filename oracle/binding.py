@@ -316,6 +316,19 @@ def algorithmic_bytes(c: dict) -> float:
     return total / max(c["samples"], 1)
 
 
+def usable_threads() -> int:
+    """Worker threads worth starting for the checkers: the affinity mask cut down to the container's CPU-time quota (cgroup
+    cpu.max).  Under a 16-CPU quota on a 256-thread host, 256 workers are slower than 16 (profiles/r04_cpu_sweep.jsonl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 _ref: Optional[RefLib] = None
 _port: Optional[PortLib] = None
 _port_libm: Optional[PortLib] = None

@@ -10,6 +10,8 @@ import mpmath as mp
 import numpy as np
 import pytest
 
+from oracle import binding
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "filter.npz")
 
 
@@ -108,7 +110,7 @@ def test_gamma_thresholds_are_the_gamma_curve(port):
     T = np.zeros(256, np.float32)
     native.check(native.lib().chunky_filter_gamma_thresholds(T.ctypes.data))
     assert T[0] == 0 and (np.diff(T[1:]) > 0).all() and 0.99 < T[255] < 1.0
-    assert port.gamma_scan(0, 0x3F900000, T, threads=os.cpu_count() or 8) == 0
+    assert port.gamma_scan(0, 0x3F900000, T, threads=binding.usable_threads()) == 0
     for lo in range(0x3F900000, 0x7F800000, 0x01000000):            # the rest of the positive floats, 65 536 at a time
         assert port.gamma_scan(lo, lo + 0xFFFF, T, threads=2) == 0
     assert port.gamma_scan(0x7F7F0000, 0x7F800000, T, threads=2) == 0   # up to +inf

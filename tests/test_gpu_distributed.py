@@ -16,6 +16,8 @@ import sys
 import numpy as np
 import pytest
 
+from oracle import binding
+
 from chunkyclplugin_amd import native, scenes
 from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
 
@@ -70,7 +72,7 @@ def test_ranks_on_one_device_reduce_to_the_single_rank_image(tmp_path, port, sin
     # and the reduced image is the oracle's on whole rows (so "equal to the single-rank image" is not two wrongs)
     rows = (5, H // 3, H // 2, H - 2)
     gids = np.concatenate([np.arange(y * W, (y + 1) * W) for y in rows]).astype(np.int32)
-    ref = port.render_gids(sc, native.java_random_ints(PASSES), gids, threads=os.cpu_count() or 8).reshape(-1, 3)[gids]
+    ref = port.render_gids(sc, native.java_random_ints(PASSES), gids, threads=binding.usable_threads()).reshape(-1, 3)[gids]
     np.testing.assert_array_equal(got.reshape(-1, 3)[gids].view(np.uint32), ref.view(np.uint32))
 
 

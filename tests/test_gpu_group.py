@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+from oracle import binding
+
 import golden_scenes as gs
 from chunkyclplugin_amd import native, scenes
 from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance
@@ -128,7 +130,7 @@ def test_group_on_the_timed_workload(gpu_instance, port):
     got = rg.read().reshape(-1, 3)
     rows = (3, 271, 540, 811, 1077)
     gids = np.concatenate([np.arange(y * W, (y + 1) * W) for y in rows]).astype(np.int32)
-    ref = port.render_gids(sc, seeds, gids, threads=os.cpu_count() or 8).reshape(-1, 3)[gids]
+    ref = port.render_gids(sc, seeds, gids, threads=binding.usable_threads()).reshape(-1, 3)[gids]
     np.testing.assert_array_equal(bits(got[gids]), bits(ref))
     assert np.isfinite(got).all() and got.any(axis=1).mean() > 0.99  # every block arrived
     rg.close()

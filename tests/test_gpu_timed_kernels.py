@@ -11,11 +11,13 @@ import os
 import numpy as np
 import pytest
 
+from oracle import binding
+
 from chunkyclplugin_amd import native, parallel, scenes
 from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
 
 pytestmark = pytest.mark.gpu
-THREADS = os.cpu_count() or 8
+THREADS = binding.usable_threads()
 ROWS = (7, 101, 263, 411, 540, 688, 799, 931, 1003, 1079)
 
 

@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 import golden_scenes as gs
+from oracle import binding
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "libm_platform.npz"))
 SCENES = ("outdoor", "indoor_sun", "entities")
@@ -65,7 +66,7 @@ def test_restatement_on_the_libm_platform_at_timed_sizes(port_libm, name):
     rows = gs.timed_rows(sc)
     gids = np.concatenate([np.arange(y * sc.width, (y + 1) * sc.width) for y in rows]).astype(np.int32)
     seeds = scenes.java_random_ints(gs.TIMED_PASSES)
-    got = port_libm.render_gids(binding.SceneHandle(sc), seeds, gids, threads=os.cpu_count() or 8).reshape(-1, 3)[gids]
+    got = port_libm.render_gids(binding.SceneHandle(sc), seeds, gids, threads=binding.usable_threads()).reshape(-1, 3)[gids]
     np.testing.assert_array_equal(bits(got), bits(GOLD["timed_" + name + "_res"].reshape(-1, 3)))
 
 

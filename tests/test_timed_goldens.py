@@ -13,7 +13,7 @@ import golden_scenes as gs
 from oracle import binding
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "timed_rows.npz"))
-THREADS = os.cpu_count() or 8
+THREADS = binding.usable_threads()
 
 
 def bits(a):

@@ -18,7 +18,7 @@ from oracle import binding  # noqa: E402
 
 sc = octree2.cached_benchmark_scene(256, 256)
 seeds = scenes.java_random_ints(16)
-threads = os.cpu_count() or 1
+threads = binding.usable_threads()
 out = {"config": "BASELINE configs[0]: benchmark/OpenCL_test, 256x256, 16 spp, sun+sky, flat-colour cubes (octree2.py)",
        "host_threads": threads, "samples": 256 * 256 * 16}
 h = binding.SceneHandle(sc)

@@ -55,9 +55,9 @@ def run(sc, name, passes=32, launches=3, world=1, ext=None, check_rows=(60, 250,
     port.counters(reset=True)
     if ext:
         with PortExt(port, sc, **ext):
-            want = port.render_gids(sc, seeds[:passes], gids, threads=os.cpu_count()).reshape(-1, 3)
+            want = port.render_gids(sc, seeds[:passes], gids, threads=binding.usable_threads()).reshape(-1, 3)
     else:
-        want = port.render_gids(sc, seeds[:passes], gids, threads=os.cpu_count()).reshape(-1, 3)
+        want = port.render_gids(sc, seeds[:passes], gids, threads=binding.usable_threads()).reshape(-1, 3)
     bps = binding.algorithmic_bytes(port.counters(enable=False, reset=True))
     same = bool(np.array_equal(got[gids].view(np.uint32), want[gids].view(np.uint32)))
     n_local = int(parallel.owned_gids(sc.width * sc.height, 0, world, 0, sc.width).size)

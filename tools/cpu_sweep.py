@@ -24,7 +24,12 @@ port.lib.port_set_pinning.restype = None
 h = binding.SceneHandle(sc)
 seeds = scenes.java_random_ints(64)
 ncpu = os.cpu_count() or 1
-threads = [int(a) for a in sys.argv[1:]] or sorted({1, 8, min(64, ncpu), min(128, ncpu), ncpu})
+try:  # the container's CPU-time quota, if any (cgroup v2)
+    _q, _p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+    quota = None if _q == "max" else int(_q) / int(_p)
+except Exception:
+    quota = None
+threads = [int(a) for a in sys.argv[1:]] or sorted({1, 8, int(quota) if quota else 8, min(64, ncpu), min(128, ncpu), ncpu})
 base = None
 for i, t in enumerate(threads):
     for pinned in ((0, 1) if i % 2 == 0 else (1, 0)):  # alternate which goes first: a cold first run must not look like an effect of pinning
@@ -49,5 +54,5 @@ for i, t in enumerate(threads):
         print(json.dumps({"threads": t, "pinned": bool(pinned), "Msamples/s": round(best, 4), "runs": [round(r, 4) for r in rates],
                           "spread": round((max(rates) - min(rates)) / best, 4), "per_thread": round(best / t, 5),
                           "efficiency_vs_first_row": round(best / t / base, 3), "samples_per_run": int(gids.size * passes),
-                          "host_cpus": ncpu}), flush=True)
+                          "host_cpus": ncpu, "cgroup_cpu_quota": quota}), flush=True)
 port.lib.port_set_pinning(0)
