@@ -154,7 +154,7 @@ def compare_golden(image, gold, width):
             "passes": int(len(gold[0])), "against": "tests/golden/timed_rows.npz (rows rendered by the reference build, oracle/_ref)"}
 
 
-def pmc_entry(info, passes_per_launch, samples_per_launch, kernel_variant):
+def pmc_entry(config, info, passes_per_launch, samples_per_launch, kernel_variant):
     """The committed PMC summary collected for exactly this launch shape, or None."""
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(tp) or kernel_variant != 0:
@@ -162,8 +162,8 @@ def pmc_entry(info, passes_per_launch, samples_per_launch, kernel_variant):
     try:
         pm = json.load(open(tp))
         for e in pm.get("entries", [pm]):
-            if (e.get("kernel_info") == [info["tree"], info["group"], int(info["bvh"]), info["pool"]] and e.get("passes_per_launch") == passes_per_launch
-                    and e.get("samples_per_launch") == samples_per_launch):
+            if (e.get("config", 2) == config and e.get("kernel_info") == [info["tree"], info["group"], int(info["bvh"]), info["pool"]]
+                    and e.get("passes_per_launch") == passes_per_launch and e.get("samples_per_launch") == samples_per_launch):
                 return e
     except Exception:
         pass
@@ -177,15 +177,21 @@ def end_to_end_leg(loader, sc, spp, make_renderer):
     out = {"spp": spp, "merge_interval": MERGE_INTERVAL}
     for label in ("cold", "warm"):
         buf = np.zeros(n, np.float64)
-        merges = []
+        merges, marks = [], []
         r.kernel_time()
         t0 = time.perf_counter()
-        got = r.render_ex(buf, 0, spp, merge_interval=MERGE_INTERVAL, merged=merges.append)
+        got = r.render_ex(buf, 0, spp, merge_interval=MERGE_INTERVAL, progress=lambda s: marks.append((s, time.perf_counter())),
+                          merged=lambda s: (merges.append(s), marks.append((-s, time.perf_counter()))))
         dt = time.perf_counter() - t0
         ms, launches = r.kernel_time()
         assert got == spp
         out[("cold_" if label == "cold" else "") + "value"] = round(sc.width * sc.height * spp / dt / 1e6, 3)
-        out[label] = {"seconds": round(dt, 5), "launches": launches, "kernel_ms": round(ms, 3), "readbacks": len(merges)}
+        # where the wall time went: [spp after the launch, ms since the start] per launch; a negative spp marks the end of a merge
+        line = [[int(s), round((t - t0) * 1e3, 2)] for s, t in marks]
+        if len(line) > 24:
+            line = line[:12] + [["..."]] + line[-11:]
+        out[label] = {"seconds": round(dt, 5), "launches": launches, "kernel_ms": round(ms, 3), "readbacks": len(merges),
+                      "host_ms": round(dt * 1e3 - ms, 3), "timeline_ms": line}
         out["readbacks"] = len(merges)
     out["unit"] = "Msamples/s"
     out["includes"] = ("launch-size climb (cold), every read-back into host memory, the double-precision merge into the sample "
@@ -426,7 +432,7 @@ def main():
         bvh_tag = ",bvh" if info["bvh"] else ""
         kernel_name = ("render_pool<%d,%d%s>+fold_kernel" % (info["tree"], info["pool"], bvh_tag) if info["pool"] >= 0 else
                        "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh"))
-        pm = pmc_entry(info, passes_per_launch, samples_per_launch, args.kernel) if not group_devices else None
+        pm = pmc_entry(args.config, info, passes_per_launch, samples_per_launch, args.kernel) if not group_devices else None
         traffic = pm.get("hbm_bytes_per_launch") if pm else None
         how = (f"{len(group_devices)} GPU(s) behind one context in one process (chunky_group_create), 16x16-pixel blocks round-robin, one gather per read-back"
                if group_devices else

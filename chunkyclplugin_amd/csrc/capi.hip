@@ -135,6 +135,7 @@ struct chunky_render {
     int timed_launches = 0;
     KernelChoice last_choice{0, 0, 0, 0, -1, 0};  // what the most recent launch ran (chunky_render_kernel_info)
     int launch_cap = 0;  // most passes one launch carries here (staging size); 0 = not determined yet
+    int reserve_passes = 0;  // the pass loop is about to climb to launches of this many passes: size the staging array once
     // on a group: one target per member (this object holds no device data), the caller's share of the image, and the buffers
     // of the read-back exchange: gather_send[i] on member i's device, gather_recv[i] on member 0's
     std::vector<chunky_render*> parts;
@@ -1373,6 +1374,19 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
         if (r->staging.bytes < need) {  // grows to the largest launch seen; launches on the stream are ordered, so it is reused
             HIP_TRY(hipStreamSynchronize(r->ctx->stream));
             r->staging.release();
+            // chunky_render_run_ex climbs 1, 8, 64 ... passes per launch: one allocation for where it is going, not four
+            const int ahead = r->reserve_passes < r->launch_cap ? r->reserve_passes : r->launch_cap;
+            if (ahead > ps.n) {
+                const size_t want = staging_floats(r->shard, r->width, r->height, ahead) * sizeof(float);
+                if (hipMalloc(&r->staging.p, want) == hipSuccess) {
+                    r->staging.bytes = want;
+                } else {
+                    (void)hipGetLastError();
+                    r->staging.p = nullptr;
+                }
+            }
+        }
+        if (r->staging.bytes < need) {
             // memory is short: shorter launches instead of a failed render (each halving halves the array)
             while (hipMalloc(&r->staging.p, need) != hipSuccess) {
                 (void)hipGetLastError();
@@ -1606,7 +1620,13 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
     int samp_spp = *scene_spp;         // sceneSpp[0], :92
     auto last_callback = std::chrono::steady_clock::now();
     if (int rc = chunky_render_reset(r)) return rc;  // new float[] passBuffer uploaded with the buffer, :61,71
-    int launch_passes = 1;             // adapts to ~80 ms per launch (below), so postRender is polled often enough
+    {   // the launches below grow to what fits 95 ms: let the first one size the staging array for that
+        const int ahead = target_spp - *scene_spp < merge_interval ? target_spp - *scene_spp : merge_interval;
+        std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
+        if (r->parts.empty()) r->reserve_passes = ahead;
+        for (chunky_render* part : r->parts) part->reserve_passes = ahead;
+    }
+    int launch_passes = 1;             // adapts to ~95 ms per launch (below), so postRender is polled often enough
     while (logical_spp < target_spp) { // :102
         int buffer_spp = 0;            // bufferSppReal
         int until_merge = target_spp - logical_spp < merge_interval ? target_spp - logical_spp : merge_interval;
@@ -1632,12 +1652,12 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
             if (cb.progress) cb.progress(cb.user, *scene_spp);
             if (cb.regenerate_camera) cb.regenerate_camera(cb.user);         // :146-148
             double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-            // passes per launch: as many as fit ~80 ms at the rate just measured (postRender is polled between launches, at least
+            // passes per launch: as many as fit ~95 ms at the rate just measured (postRender is polled between launches, at least
             // every 100 ms where a launch allows it), at most eight times the last launch — a launch of few passes overstates
             // the time per pass (its fixed costs), so the sequence climbs 1, 8, 64, ... and settles; it comes down the same way
             {
                 const double per_pass = ms / (double)m;
-                int want = per_pass > 0.0 ? (int)(80.0 / per_pass) : kMaxPassesPerLaunch;
+                int want = per_pass > 0.0 ? (int)(95.0 / per_pass) : kMaxPassesPerLaunch;  // a launch stays under the 100 ms of :153
                 if (want > launch_passes * 8) want = launch_passes * 8;
                 if (want > kMaxPassesPerLaunch) want = kMaxPassesPerLaunch;
                 if (want < 1) want = 1;
