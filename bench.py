@@ -484,12 +484,27 @@ def main():
             out["image_check"] = image_check
 
     # ---- N > 1: rank 0 alone opens all GPUs behind one context — the in-process path a JVM binds (the others wait) ----------
-    if world > 1 and on_gpu and not args.one_device and not args.no_extras:
+    if world > 1 and not args.no_extras:
+        # (the one-device rig runs it too, with members that share GPU 0)  the other ranks wait on the rendezvous STORE (host side), not in a collective: an RCCL barrier would keep a spinning
+        # kernel on every GPU the group is about to render on
+        import datetime
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
         if rank == 0:
             try:
-                out["group_check"] = group_leg(sorted(set(devices_seen)), sc, seeds, passes, gold, args.kernel)
+                out["group_check"] = group_leg(sorted(devices_seen), sc, seeds, passes, gold, args.kernel)
             except Exception as e:  # first contact with real multi-GPU hardware: report, do not fail the bench
                 out["group_check"] = {"error": f"{type(e).__name__}: {e}"}
+            if store is not None:
+                store.set("chunky_group_check", "done")
+        elif store is not None:
+            torch.cuda.synchronize()
+            try:
+                store.wait(["chunky_group_check"], datetime.timedelta(minutes=10))
+            except Exception:
+                pass
         dist.barrier()
 
     if rank == 0:

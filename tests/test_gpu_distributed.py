@@ -125,6 +125,10 @@ def test_headline_line_checks_its_own_image(tmp_path):
     assert line["config"]["baseline_config"] == 2 and line["config"]["passes_per_step"] == 256
     chk = line["image_check"]
     assert chk["bit_identical"] and chk["pixels"] == 4 * 1920 and chk["pixels_differing"] == 0, chk
+    # and rank 0 then opened "all GPUs" behind one context (here: two members on GPU 0) while rank 1 waited on the store
+    g = line["group_check"]
+    assert "error" not in g, g
+    assert g["members"] == 2 and g["peer_status"] == [0, 0] and g["gather_ms"] > 0 and g["image_check"]["bit_identical"], g
 
 
 def _run_single(args):

@@ -27,8 +27,9 @@ lookups = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / tcp_cycles if "TCP_TOTAL_CACHE_ACC
 hbm = d.get("hbm_bytes_per_launch")
 launch_s = roof["launch_ms"] * 1e-3
 if lookups is not None and lookups > 0.85:
-    limiter = ("the L1s' tag look-ups (%.2f per cycle and L1, about one at most): the kernel runs at the chip's rate for uncoalesced "
-               "16-byte gathers; VALU lanes %.0f %% useful, waves waiting %.0f %% of their cycles" % (lookups, 100 * issue * lane, 100 * wait))
+    limiter = ("the L1s' tag look-ups (%.2f per cycle and L1, about one at most: every lane of a scattered load is a look-up of its own); "
+               "VALU lanes %.0f %% useful, waves waiting %.0f %% of their cycles, L2 requests at %.0f %% of its bandwidth"
+               % (lookups, 100 * issue * lane, 100 * wait, 100 * c["TCC_REQ_sum"] * 64 / (cycles / 2.4e9) / 34.5e12))
 else:
     limiter = ("issue + latency: VALU issue slots (%.0f %% used at %.0f %% of the lanes) and the L1's tag look-ups (%.2f per cycle, about one "
                "at most) are both more than half used while %.0f %% of the wave cycles are waits on dependent reads; HBM is at %.1f %% of peak"
