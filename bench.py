@@ -407,6 +407,42 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # ---- scenes with entity BVHs: the same steps once more with CHUNKY_OPT_BVH_CULL_BEHIND (an EXTENSION, default off: children
+    #      entirely behind the ray origin count as missed — the reference walks them), reported beside `value`, never as it ----
+    behind_cull = None
+    if info["bvh"] and not args.no_extras and not args.emulate_world:
+        r.set_option(native.OPT_BVH_CULL_BEHIND, 1)
+        r.reset()
+        barrier()
+        r.kernel_time()
+        reduce_ms.clear()
+        t1 = time.perf_counter()
+        run_steps(args.steps, args.warmup * passes)
+        barrier()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt2], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        ms2, n2 = r.kernel_time()
+        check2 = None
+        if gold is not None:
+            r.reset()
+            r.render_passes(gold[0], sync=False)
+            read_back()
+            if rank == 0:
+                check2 = compare_golden(r.read() if group_devices else image.cpu().numpy(), gold, sc.width)
+        r.set_option(native.OPT_BVH_CULL_BEHIND, 0)
+        if rank == 0:
+            behind_cull = {"option": "CHUNKY_OPT_BVH_CULL_BEHIND = 1 (extension, default 0; include/chunky_hip.h)",
+                           "value": round(n_pix * args.steps * passes / dt2 / 1e6, 3), "unit": "Msamples/s",
+                           "launch_ms": round(ms2 / max(n2, 1), 4), "image_check": check2,
+                           "note": "the reference's walk visits every box the ray's LINE pierces, half of them behind the origin; with the "
+                                   "option those count as missed.  Identical to the reference build's rows here, but not the reference's "
+                                   "result by construction (EXPERIMENTS.md 4.4): `value` above is the reference's walk"}
+        if world > 1:
+            dist.barrier()
+
     if rank == 0:
         local_slots = int(parallel.owned_gids(n_pix, 0, args.emulate_world or world, args.tile, sc.width).size)  # pixels rank 0 renders
         # an emulated share renders only rank 0's tiles: count what was rendered, and say so
@@ -482,6 +518,8 @@ def main():
             out["per_rank"] = per_rank
         if image_check is not None:
             out["image_check"] = image_check
+        if behind_cull is not None:
+            out["extension_behind_cull"] = behind_cull
 
     # ---- N > 1: rank 0 alone opens all GPUs behind one context — the in-process path a JVM binds (the others wait) ----------
     if world > 1 and not args.no_extras:

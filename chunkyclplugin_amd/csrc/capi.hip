@@ -1044,6 +1044,7 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     v->sv = f3{svx, svy, svz};
     v->su = f3{rt_cross_c(svy, swz, svz, swy), rt_cross_c(svz, swx, svx, swz), rt_cross_c(svx, swy, svy, swx)};
     v->sun_radius_cos = rt_cos(0.03f);
+    v->bvh_cull = 0;  // a render target's option: set by its launch sites
     v->world_bvh_empty = (s->world_empty || !s->world_bvh.p) ? 1 : 0;
     v->actor_bvh_empty = (s->actor_empty || !s->actor_bvh.p) ? 1 : 0;
     if (s->wide_dirty && s->wide_meta.nlev > 0) {
@@ -1260,6 +1261,10 @@ extern "C" int chunky_render_set_option(chunky_render* r, int option, int32_t va
             if (value != 0 && value != 1) return fail(CHUNKY_E_INVALID, "emitter NEE: 0 or 1");
             r->opts.nee = value;
             break;
+        case CHUNKY_OPT_BVH_CULL_BEHIND:
+            if (value != 0 && value != 1) return fail(CHUNKY_E_INVALID, "BVH cull: 0 or 1");
+            r->opts.bvh_cull = value;
+            break;
         default: return fail(CHUNKY_E_INVALID, "unknown option %d", option);
     }
     return CHUNKY_OK;
@@ -1348,6 +1353,7 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
     if (!r->have_camera) return fail(CHUNKY_E_STATE, "render_passes before set_camera");
     SceneView S;
     if (int rc = scene_view(r->scene, &S, r->opts.nee != 0)) return rc;
+    S.bvh_cull = r->opts.bvh_cull;
     if (opts_extended(r->opts)) {  // the extensions exist in render_pool only
         const bool bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
         if ((r->kernel_variant & (1 | 2 | 4 | 8)) || (bvh && !(S.bvh_rec && S.tri_rec && S.mat8)))
@@ -1544,6 +1550,7 @@ extern "C" int chunky_render_preview(chunky_render* r, int32_t* argb_out) {
     if (!r->have_camera) return fail(CHUNKY_E_STATE, "preview before set_camera");
     SceneView S;
     if (int rc = scene_view(r->scene, &S)) return rc;
+    S.bvh_cull = r->opts.bvh_cull;
     DevBuf out;
     size_t bytes = (size_t)r->width * r->height * 4;
     HIP_TRY(hipMalloc(&out.p, bytes));
@@ -1566,6 +1573,7 @@ extern "C" int chunky_render_trace_records(chunky_render* r, int32_t seed, const
         if (gids[i] < 0 || gids[i] >= r->width * r->height) return fail(CHUNKY_E_INVALID, "trace_records: gid %d outside the image", gids[i]);
     SceneView S;
     if (int rc = scene_view(r->scene, &S)) return rc;
+    S.bvh_cull = r->opts.bvh_cull;
     DevBuf dg, dr, dc, dq;
     hipStream_t st = r->ctx->stream;
     HIP_TRY(dg.upload(gids, (size_t)n * 4, st));

@@ -53,10 +53,15 @@ DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) {
     const float limit = L.shadow ? L.bvh_dist : L.h.distance;
     if (inner) {
         const int first = r0.x, second = r0.y;
-        const float t1 = box_quick(as_float(r1.x), as_float(r1.y), as_float(r1.z), as_float(r1.w), as_float(r2.x), as_float(r2.y), L.o, L.inv);
-        const float t2 = box_quick(as_float(r2.z), as_float(r2.w), as_float(r3.x), as_float(r3.y), as_float(r3.z), as_float(r3.w), L.o, L.inv);
-        const bool miss1 = (t1 != t1) || t1 > limit;
-        const bool miss2 = (t2 != t2) || t2 > limit;
+        float f1, f2;
+        const float t1 = box_quick_far(as_float(r1.x), as_float(r1.y), as_float(r1.z), as_float(r1.w), as_float(r2.x), as_float(r2.y), L.o, L.inv, f1);
+        const float t2 = box_quick_far(as_float(r2.z), as_float(r2.w), as_float(r3.x), as_float(r3.y), as_float(r3.z), as_float(r3.w), L.o, L.inv, f2);
+        bool miss1 = (t1 != t1) || t1 > limit;
+        bool miss2 = (t2 != t2) || t2 > limit;
+        if (S.bvh_cull) {  // (extension, wave-uniform) a child entirely behind the origin counts as missed
+            miss1 |= f1 < 0;
+            miss2 |= f2 < 0;
+        }
         if (miss1 & miss2) return rbvh_pop(S, L, K);
         const bool go_first = !miss1 & (miss2 | (t1 < t2));  // K/bvh.h:86-103: the first child is the near one only when t1 < t2
         if (!miss1 & !miss2) {

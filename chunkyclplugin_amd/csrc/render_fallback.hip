@@ -134,12 +134,17 @@ DEV int bvh_phase(const SceneView& S, LaneState& L, LdsStack& stack) {
     const int* a = bvh + first;
     const int* b = bvh + second;
     const int head_a = a[0], head_b = b[0];
-    float t1 = box_quick(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
-                         as_float(a[6]), L.o, L.inv);
-    float t2 = box_quick(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
-                         as_float(b[6]), L.o, L.inv);
-    const bool miss1 = (t1 != t1) || t1 > limit;
-    const bool miss2 = (t2 != t2) || t2 > limit;
+    float f1, f2;
+    float t1 = box_quick_far(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
+                             as_float(a[6]), L.o, L.inv, f1);
+    float t2 = box_quick_far(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
+                             as_float(b[6]), L.o, L.inv, f2);
+    bool miss1 = (t1 != t1) || t1 > limit;
+    bool miss2 = (t2 != t2) || t2 > limit;
+    if (S.bvh_cull) {  // CHUNKY_OPT_BVH_CULL_BEHIND
+        miss1 |= f1 < 0;
+        miss2 |= f2 < 0;
+    }
     if (miss1 & miss2) return bvh_pop(S, L, stack);
     // near child first; the other one is pushed when both are hit (K/bvh.h:86-103: the first child is the near one
     // only when t1 < t2)

@@ -99,6 +99,9 @@ struct SceneView {
     // in pre-order — the list of oracle/port.c port_list_emitters
     const int4* __restrict__ emitters;
     int n_emitters;
+    // CHUNKY_OPT_BVH_CULL_BEHIND (extension, default 0 = the reference's walk): children whose box lies entirely behind the ray
+    // origin count as missed.  The reference's quick test (K/primitives.h:30-48) has no such exit and walks them.
+    int bvh_cull;
 };
 
 struct CameraView {
@@ -120,6 +123,7 @@ struct RenderOpts {
     int emitters;         // 1 as the reference; 0 = emittersEnabled false
     int bsdf;             // 1: specular / metal / roughness from material word 5
     int nee;              // 1: emitter next-event estimation
+    int bvh_cull;         // 1: CHUNKY_OPT_BVH_CULL_BEHIND (travels to the kernels in SceneView::bvh_cull)
 };
 __host__ __device__ inline bool opts_extended(const RenderOpts& O) { return O.sun_sampling != -1 || O.emitters != 1 || O.bsdf != 0 || O.nee != 0; }
 
@@ -152,6 +156,14 @@ DEV float slab_far(const Slabs& s) {
 DEV float box_quick(float x0, float x1, float y0, float y1, float z0, float z1, f3 o, f3 inv) {
     Slabs s = slabs(x0, x1, y0, y1, z0, z1, o, inv);
     float tn = slab_near(s), tf = slab_far(s);
+    return (tf < tn) ? rt_nan() : tn;
+}
+// the same test, also handing out where the ray's line leaves the box (CHUNKY_OPT_BVH_CULL_BEHIND: a box whose far end lies
+// behind the origin cannot hold a hit)
+DEV float box_quick_far(float x0, float x1, float y0, float y1, float z0, float z1, f3 o, f3 inv, float& tf) {
+    Slabs s = slabs(x0, x1, y0, y1, z0, z1, o, inv);
+    float tn = slab_near(s);
+    tf = slab_far(s);
     return (tf < tn) ? rt_nan() : tn;
 }
 // AABB_exit
@@ -501,12 +513,17 @@ DEV bool bvh_hit(const SceneView& S, const int* __restrict__ bvh, f3 o, f3 d, Hi
             int second = head;
             const int* a = bvh + cur + 7;
             const int* b = bvh + second;
-            float t1 = box_quick(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
-                                 as_float(a[6]), o, inv);
-            float t2 = box_quick(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
-                                 as_float(b[6]), o, inv);
+            float f1, f2;
+            float t1 = box_quick_far(as_float(a[1]), as_float(a[2]), as_float(a[3]), as_float(a[4]), as_float(a[5]),
+                                     as_float(a[6]), o, inv, f1);
+            float t2 = box_quick_far(as_float(b[1]), as_float(b[2]), as_float(b[3]), as_float(b[4]), as_float(b[5]),
+                                     as_float(b[6]), o, inv, f2);
             bool miss1 = (t1 != t1) || t1 > h.distance;
             bool miss2 = (t2 != t2) || t2 > h.distance;
+            if (S.bvh_cull) {
+                miss1 |= f1 < 0;
+                miss2 |= f2 < 0;
+            }
             if (miss1) {
                 if (miss2) {
                     if (to_visit == 0) break;

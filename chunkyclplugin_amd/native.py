@@ -27,7 +27,7 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("material", "<i4"), ("distance", "<f4"), 
 
 PALETTE_BLOCK, PALETTE_MATERIAL, PALETTE_AABB, PALETTE_QUAD, PALETTE_TRIG = range(5)
 BVH_WORLD, BVH_ACTOR = 0, 1
-OPT_DRAW_DEPTH, OPT_MAX_DEPTH, OPT_EMITTER_SCALE, OPT_KERNEL, OPT_SUN_SAMPLING, OPT_EMITTERS, OPT_BSDF, OPT_EMITTER_NEE = range(8)
+OPT_DRAW_DEPTH, OPT_MAX_DEPTH, OPT_EMITTER_SCALE, OPT_KERNEL, OPT_SUN_SAMPLING, OPT_EMITTERS, OPT_BSDF, OPT_EMITTER_NEE, OPT_BVH_CULL_BEHIND = range(9)
 PEER_LOCAL, PEER_DIRECT, PEER_STAGED = 0, 1, 2
 E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_ABORTED = -1, -2, -3, -4, -5
 

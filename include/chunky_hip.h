@@ -145,7 +145,15 @@ typedef enum chunky_option {
     CHUNKY_OPT_SUN_SAMPLING = 4,    /* int: -1 as the reference (PackedSun flag bit 0), 0 never, 1 always (Chunky sunEnabled) */
     CHUNKY_OPT_EMITTERS = 5,        /* int: 1 (default) / 0 = Chunky emittersEnabled false */
     CHUNKY_OPT_BSDF = 6,            /* int: 0 (default) / 1 = specular, metalness, roughness from material word 5 (PackedMaterial.java:69-71) */
-    CHUNKY_OPT_EMITTER_NEE = 7      /* int: 0 (default) / 1 = next-event estimation towards the scene's emitter blocks */
+    CHUNKY_OPT_EMITTER_NEE = 7,     /* int: 0 (default) / 1 = next-event estimation towards the scene's emitter blocks */
+    /* EXTENSION, not the reference's walk: 1 = in the entity-BVH traversal a child whose box lies entirely BEHIND the ray origin
+     * (the far end of the slab test is negative) counts as missed.  The reference's quick test (K/primitives.h:30-48, used by
+     * K/bvh.h:72-85) has no such exit: it descends into every box the ray's LINE pierces, and about half of its node visits and
+     * triangle tests are spent behind the origin (EXPERIMENTS.md 4.4).  A triangle there can only be "hit" when rounding noise
+     * carries its barycentric test across (the reference admits |det| down to 5e-6), so the image is the reference's wherever the
+     * reference's own arithmetic is meaningful — no trace of 41 million differed — but it is not the reference's BY CONSTRUCTION,
+     * which is why this is an option and 0 the default.  Specification: oracle/port.c with port_set_bvh_cull(1). */
+    CHUNKY_OPT_BVH_CULL_BEHIND = 8  /* int: 0 (default) / 1 */
 } chunky_option;
 int chunky_render_set_option(chunky_render* r, int option, int32_t value);
 

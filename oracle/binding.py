@@ -189,6 +189,24 @@ class PortOptions:
         return False
 
 
+class PortCull:
+    """with PortCull(port): the C restatement walks the entity BVHs with CHUNKY_OPT_BVH_CULL_BEHIND (children entirely behind the
+    ray origin count as missed) — the specification of that option; the reference's walk again on exit."""
+
+    def __init__(self, port, on: bool = True):
+        self.port, self.on = port, on
+        port.lib.port_set_bvh_cull.argtypes = [C.c_int]
+        port.lib.port_set_bvh_cull.restype = None
+
+    def __enter__(self):
+        self.port.lib.port_set_bvh_cull(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *exc):
+        self.port.lib.port_set_bvh_cull(0)
+        return False
+
+
 class PortExt:
     """with PortExt(port, scene, sun_sampling=.., emitters=.., bsdf=.., nee=..): the C restatement renders with the
     EXPERIMENTAL light-transport options of DESIGN.md section 9 (oracle/port.c trace_sample_ext is their specification);

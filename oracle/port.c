@@ -418,6 +418,12 @@ static float triangle_hit(const int32_t* t, float best, v3 o, v3 dir, v3* normal
 
 static inline float as_f(int32_t i) { return rt_u2f((unsigned)i); }
 
+/* EXTENSION (CHUNKY_OPT_BVH_CULL_BEHIND, default off): a child whose box lies entirely behind the ray origin — AABB_exit
+ * (K/primitives.h:52-61) negative — counts as missed.  The reference walks such boxes (its quick test only asks whether the
+ * ray's LINE pierces the box before the current hit); this is the specification of the option, not of the reference. */
+static int g_bvh_cull = 0;
+void port_set_bvh_cull(int on) { g_bvh_cull = on; }
+
 /* K/bvh.h:22-113 */
 static int bvh_intersect(const OracleScene* s, const int32_t* bvh, const Path* p, Record* rec) {
     if (bvh[0] == 0 && rt_isnan(as_f(bvh[1])) && rt_isnan(as_f(bvh[2])) && rt_isnan(as_f(bvh[3])) &&
@@ -458,6 +464,10 @@ static int bvh_intersect(const OracleScene* s, const int32_t* bvh, const Path* p
             float t2 = box_quick(&b2, o, inv);
             int miss1 = rt_isnan(t1) || t1 > rec->distance;
             int miss2 = rt_isnan(t2) || t2 > rec->distance;
+            if (g_bvh_cull) {
+                if (box_exit(&b1, o, inv) < 0) miss1 = 1;
+                if (box_exit(&b2, o, inv) < 0) miss2 = 1;
+            }
             if (miss1) {
                 if (miss2) {
                     if (to_visit == 0) break;

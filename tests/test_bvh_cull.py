@@ -1,0 +1,116 @@
+"""CHUNKY_OPT_BVH_CULL_BEHIND — an EXTENSION, default off (include/chunky_hip.h): in the entity-BVH walk a child whose box lies
+entirely behind the ray origin counts as missed.  The reference has no such exit (K/primitives.h:30-48 asks only whether the ray's
+LINE pierces the box before the current hit) and spends about half of its node visits behind the origin.  The option's
+specification is oracle/port.c with port_set_bvh_cull(1); the HIP kernels must reproduce it bit for bit, and on every scene and seed
+tried it also reproduces the REFERENCE bit for bit — a triangle behind the origin is only ever "hit" by rounding noise — which
+these tests pin on the golden and timed fixtures (rendered by the reference build without any culling).  That identity is an
+observation, not a theorem (EXPERIMENTS.md 4.4): hence an option."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_scenes as gs
+from chunkyclplugin_amd import native
+from oracle import binding
+from oracle.binding import PortCull
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_specification_skips_half_the_walk_and_keeps_the_image(port):
+    sc = gs.make("entities")
+    g = np.load(os.path.join(GOLD, "entities.npz"))
+    port.counters(enable=True, reset=True)
+    plain = port.render_passes(sc, g["seeds"])
+    c0 = port.counters(reset=True)
+    with PortCull(port):
+        culled = port.render_passes(sc, g["seeds"])
+    c1 = port.counters(enable=False, reset=True)
+    np.testing.assert_array_equal(bits(plain), bits(g["res"]))
+    np.testing.assert_array_equal(bits(culled), bits(g["res"]))       # the reference build's image, with far fewer visits
+    assert c1["bvh_inner"] < 0.9 * c0["bvh_inner"] and c1["tri"] < 0.9 * c0["tri"], (c0, c1)  # (a small BVH: a fifth; the timed one: half)
+    assert c1["samples"] == c0["samples"] and c1["node"] == c0["node"]  # nothing else changes
+    # and the option is off again after the block
+    port.counters(enable=True, reset=True)
+    port.render_passes(sc, g["seeds"])
+    assert port.counters(enable=False, reset=True)["bvh_inner"] == c0["bvh_inner"]
+
+
+def test_specification_on_the_timed_entity_rows(port):
+    """configs[4] as timed (100 000 + 5 000 triangles, 1920x1080): the culled walk gives the reference build's rows."""
+    G = np.load(os.path.join(GOLD, "timed_rows.npz"))
+    sc = gs.timed_view("entities")
+    rows = G["entities_rows"]
+    gids = np.concatenate([np.arange(y * sc.width, (y + 1) * sc.width) for y in rows]).astype(np.int32)
+    with PortCull(port):
+        got = port.render_gids(binding.SceneHandle(sc), G["seeds"], gids, threads=binding.usable_threads()).reshape(-1, 3)[gids]
+    np.testing.assert_array_equal(bits(got), bits(G["entities_res"].reshape(-1, 3)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 8, 1, 2])
+def test_hip_reproduces_the_specification_and_the_reference(gpu_instance, port, variant):
+    """Every kernel family with the option on — the pool kernel's record walk (0), round 1's voted walk (8), the packed walk of
+    the reference octree layout (1) and one lane per path (2): the oracle's culled image, the reference's golden image and the
+    golden per-trace records."""
+    from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
+    g = np.load(os.path.join(GOLD, "entities.npz"))
+    sc = gs.make("entities")
+    loader = HipSceneLoader(gpu_instance)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, sc.width, sc.height)
+    r.set_camera(sc.projector_type, sc.camera)
+    r.set_option(native.OPT_KERNEL, variant)
+    r.set_option(native.OPT_BVH_CULL_BEHIND, 1)
+    r.render_passes(g["seeds"])
+    assert r.kernel_info()["bvh"]
+    got = r.read()
+    with PortCull(port):
+        np.testing.assert_array_equal(bits(got), bits(port.render_passes(sc, g["seeds"])))
+    np.testing.assert_array_equal(bits(got), bits(g["res"]))
+    np.testing.assert_array_equal(r.preview(), g["preview"])
+    rec, cnt, rad = r.trace_records(int(g["seeds"][0]), gs.RECORD_GIDS)
+    np.testing.assert_array_equal(cnt, g["counts"])
+    for i in range(len(gs.RECORD_GIDS)):
+        n = int(cnt[i])
+        assert rec[i, :n].tobytes() == g["records"][i, :n].tobytes()
+    np.testing.assert_array_equal(bits(rad), bits(g["radiance"]))
+    with pytest.raises(Exception):
+        r.set_option(native.OPT_BVH_CULL_BEHIND, 2)
+    r.close()
+    loader.close()
+
+
+@pytest.mark.gpu
+def test_hip_culled_walk_at_the_timed_size(gpu_instance):
+    """configs[4] at 1920x1080 with the option: the timed instantiation, the reference build's rows, and a launch that is
+    markedly shorter than the reference's walk."""
+    from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
+    G = np.load(os.path.join(GOLD, "timed_rows.npz"))
+    sc = gs.timed_view("entities")
+    loader = HipSceneLoader(gpu_instance)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, sc.width, sc.height)
+    r.set_camera(sc.projector_type, sc.camera)
+    ms = {}
+    rows = G["entities_rows"]
+    gids = np.concatenate([np.arange(y * sc.width, (y + 1) * sc.width) for y in rows]).astype(np.int32)
+    for cull in (0, 1):
+        r.set_option(native.OPT_BVH_CULL_BEHIND, cull)
+        r.reset()
+        r.render_passes(G["seeds"])
+        r.kernel_time()
+        r.reset()
+        r.render_passes(G["seeds"])
+        ms[cull] = r.kernel_time()[0]
+        info = r.kernel_info()
+        assert (info["tree"], info["bvh"]) == (17, True) and info["pool"] > 0
+        np.testing.assert_array_equal(bits(r.read().reshape(-1, 3)[gids]), bits(G["entities_res"].reshape(-1, 3)))
+    assert ms[1] < 0.8 * ms[0], ms
+    r.close()
+    loader.close()

@@ -159,3 +159,8 @@ def test_other_baseline_configs_through_the_bench(config, kernel):
     assert line["config"]["baseline_config"] == config and line["roofline"]["kernel"] == kernel, line["roofline"]
     assert line["image_check"]["bit_identical"], line["image_check"]
     assert line["end_to_end"]["value"] > 0 and line["roofline"]["frac"] > 0 and line["value"] > 0
+    if config == 4:  # scenes with entities also report the behind-the-ray cull (an extension) beside the reference's walk
+        x = line["extension_behind_cull"]
+        assert x["value"] > 1.3 * line["value"] and x["image_check"]["bit_identical"], x
+    else:
+        assert "extension_behind_cull" not in line

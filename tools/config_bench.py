@@ -9,6 +9,7 @@ rows against the oracle AT THE TIMED PASS COUNT (the instantiation that is timed
   entities    configs[4]  32x32-chunk world + 100 000 world / 5 000 actor triangles, 1920x1080 on one GPU
   entities4k  configs[4]  the same at 3840x2160, rank 0's share of an 8-GPU tile split (what one GPU of the stated config renders)
   entities1m  configs[4]  1 000 000 world triangles (the upper end of the configuration's 10^5 - 10^6 range), 1920x1080 (on request)
+  entities_cull / entities1m_cull   the two entity worlds with CHUNKY_OPT_BVH_CULL_BEHIND (extension; checked against its own oracle mode)
 
     python tools/config_bench.py [names...] > profiles/rNN_config_bench.jsonl"""
 import json
@@ -32,7 +33,7 @@ def run(sc, name, passes=32, launches=3, world=1, ext=None, check_rows=(60, 250,
     r.set_camera(sc.projector_type, sc.camera)
     r.set_shard(0, world, 0)   # 16 x 16-pixel blocks, as bench.py --gpus N
     for k, v in (ext or {}).items():
-        r.set_option({"nee": native.OPT_EMITTER_NEE, "bsdf": native.OPT_BSDF}[k], v)
+        r.set_option({"nee": native.OPT_EMITTER_NEE, "bsdf": native.OPT_BSDF, "cull": native.OPT_BVH_CULL_BEHIND}[k], v)
     seeds = native.java_random_ints(passes * (launches + 1))
     r.render_passes(seeds[:passes])
     r.kernel_time()
@@ -53,7 +54,10 @@ def run(sc, name, passes=32, launches=3, world=1, ext=None, check_rows=(60, 250,
     port = binding.port()
     port.counters(enable=True, reset=True)
     port.counters(reset=True)
-    if ext:
+    if ext and "cull" in ext:
+        with binding.PortCull(port):
+            want = port.render_gids(sc, seeds[:passes], gids, threads=binding.usable_threads()).reshape(-1, 3)
+    elif ext:
         with PortExt(port, sc, **ext):
             want = port.render_gids(sc, seeds[:passes], gids, threads=binding.usable_threads()).reshape(-1, 3)
     else:
@@ -86,15 +90,20 @@ if __name__ == "__main__":
     if "indoor_nee" in which:
         res.append(run(scenes.indoor_room(size=64, width=1920, img_height=1080), "configs[3] with emitter NEE (extension)", passes=32,
                        ext={"nee": 1}))
-    if "entities" in which or "entities4k" in which:
+    if "entities" in which or "entities4k" in which or "entities_cull" in which:
         base = scenes.cached_outdoor_world(chunks=32, height=256)
         sc = scenes.add_entities(base, 100000, seed=11, actor_tris=5000, region=((40, 90, 40), (470, 170, 470)))
         if "entities" in which:
             res.append(run(sc, "configs[4] at 1920x1080 on one GPU", passes=16, launches=2))
+        if "entities_cull" in which:
+            res.append(run(sc, "configs[4] at 1920x1080 with CHUNKY_OPT_BVH_CULL_BEHIND (extension)", passes=16, launches=2, ext={"cull": 1}))
         if "entities4k" in which:
             res.append(run(sc.with_view(3840, 2160), "configs[4] at 3840x2160, rank 0 of 8", passes=16, launches=2, world=8))
     if "entities1m" in which:   # the upper end of configs[4]'s range: 10^6 world triangles
         res.append(run(scenes.cached_entity_world(1000000), "configs[4] with 1 000 000 world triangles, 1920x1080 on one GPU", passes=8, launches=2,
                        check_rows=(250, 630, 1010)))
+    if "entities1m_cull" in which:
+        res.append(run(scenes.cached_entity_world(1000000), "configs[4] with 1 000 000 world triangles and CHUNKY_OPT_BVH_CULL_BEHIND (extension)",
+                       passes=8, launches=2, check_rows=(250, 630, 1010), ext={"cull": 1}))
     for x in res:
         print(json.dumps(x), flush=True)
