@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chunkyclplugin_amd import native, parallel, scenes  # noqa: E402
 from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance  # noqa: E402
 from oracle import binding  # noqa: E402
-from oracle.binding import PortExt, PortOptions  # noqa: E402
+from oracle.binding import PortCull, PortExt, PortOptions  # noqa: E402
 
 VARIANTS = [0, 0, 0, 0, 1, 2, 3, 64, 128, 8, 9, 8 | 16, 8 | 32, 8 | 48]
 
@@ -52,11 +52,19 @@ def main():
         draw, depth, scale = int(rng.choice([256, 256, 40, 3])), int(rng.choice([5, 5, 1, 2, 9])), float(rng.choice([13.0, 13.0, 0.0, 2.5]))
         world = int(rng.choice([1, 1, 2, 3, 8]))
         rank, tile = int(rng.integers(0, world)), int(rng.choice([256, 64, 100]))
-        if variant in (0, 64, 128) and rng.random() < 0.5:
-            tile = 0  # 16 x 16 blocks (the pool kernel only)
+        if rng.random() < (0.5 if variant in (0, 64, 128) else 0.25):
+            tile = 0  # 16 x 16 blocks: mapped by the pool kernel itself, handed to the other kernels as a pixel list
         seeds = native.java_random_ints(passes, seed=int(rng.integers(0, 10 ** 6)))
         # a fifth of the pool-kernel cases run on a multi-member group: its members split the share again, the read-back gathers
-        on_group = int(rng.choice([2, 3])) if (variant in (0, 64, 128) and rng.random() < 0.2) else 0
+        # (any kernel variant: members hold block shares, which the fallback kernels render from a pixel list; a large draw depth
+        # sends the pool kernel's cases to the fallback too)
+        on_group = int(rng.choice([2, 3])) if rng.random() < 0.2 else 0
+        if not ext and rng.random() < 0.05:
+            draw = 70000
+        # entity-BVH placement (addresses only) and the behind-the-ray cull (an extension with its own oracle mode)
+        layout = str(rng.choice(["0,0", "0,0", "3,4", "64,8", "4096,32"]))
+        os.environ["CHUNKY_BVH_LAYOUT"] = layout
+        cull = int(ents > 0 and rng.random() < 0.3)
         loader = HipSceneLoader(groups[on_group] if on_group else inst)
         loader.load_packed(sc)
         r = HipPathTracingRenderer(loader, w, h)
@@ -67,12 +75,13 @@ def main():
         r.set_option(native.OPT_EMITTER_SCALE, scale)
         for k, v in ext.items():
             r.set_option({"sun_sampling": native.OPT_SUN_SAMPLING, "emitters": native.OPT_EMITTERS, "bsdf": native.OPT_BSDF, "nee": native.OPT_EMITTER_NEE}[k], v)
+        r.set_option(native.OPT_BVH_CULL_BEHIND, cull)
         r.set_shard(rank, world, tile)
         r.render_passes(seeds, first_buffer_spp=first)
         got = r.read()
         own = parallel.owned_gids(w * h, rank, world, tile, w)
         want = np.zeros(3 * w * h, np.float32)
-        with PortOptions(port, draw, depth, scale):
+        with PortOptions(port, draw, depth, scale), PortCull(port, on=bool(cull)):
             if ext:
                 with PortExt(port, sc, **ext):
                     port.render_gids(sc, seeds, own, first_spp=first, res=want)
@@ -82,7 +91,7 @@ def main():
             bad += 1
             diff = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
             print(f"FAIL it={it} seed={seed0 + it} size={size} ents={ents} view={w}x{h} variant={variant} passes={passes} first={first} "
-                  f"draw={draw} depth={depth} scale={scale} shard={rank}/{world}/{tile} group={on_group} ext={ext} kernel={r.kernel_info()} ndiff={diff.size} first_diff={diff[:4]}", flush=True)
+                  f"draw={draw} depth={depth} scale={scale} shard={rank}/{world}/{tile} group={on_group} ext={ext} layout={layout} cull={cull} kernel={r.kernel_info()} ndiff={diff.size} first_diff={diff[:4]}", flush=True)
         r.close()
         loader.close()
     print(f"fuzz: {n_iter} configurations from seed {seed0}, {bad} differed")
