@@ -131,3 +131,21 @@ def test_hip_classes_call_the_patched_surface(patched):
     assert set(call_arities(callers, r"new ClCamera")) == {1}
     assert set(call_arities(callers, r"camera\.apply")) == {1}
     assert set(call_arities(callers, r"camera\.generate")) == {2}
+
+
+def test_java_sources_lex_cleanly(patched):
+    """No JDK here: the closest thing to a compiler front end in the image is Pygments' Java lexer.  Every file under java/ and the
+    three patched classes must lex without a single error token, every string / char literal must close, and every
+    `import dev.thatredox.chunkynative.hip.X` must name a class that exists under java/."""
+    pygments = pytest.importorskip("pygments")
+    from pygments.lexers import JavaLexer
+    from pygments.token import Error
+    sources = {f: open(os.path.join(JAVA, f)).read() for f in sorted(os.listdir(JAVA)) if f.endswith(".java")}
+    sources.update({k + ".java (patched)": v for k, v in patched.items()})
+    have = {f[:-5] for f in os.listdir(JAVA) if f.endswith(".java")}
+    for name, src in sources.items():
+        bad = [v for t, v in JavaLexer().get_tokens(src) if t is Error]
+        assert not bad, (name, bad[:5])
+        for cls in re.findall(r"import dev\.thatredox\.chunkynative\.hip\.(\w+);", src):
+            assert cls in have, (name, cls)
+        assert re.search(r"^package dev\.thatredox\.chunkynative\.", src, flags=re.M), name

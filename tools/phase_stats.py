@@ -17,6 +17,11 @@ if os.environ.get("CHUNKY_STATS_MODELS") == "0":  # the same world with no slab 
 sc = scenes.cached_outdoor_world(chunks=32, height=256, **kw)
 if os.environ.get("CHUNKY_STATS_SCENE") == "entities":  # BASELINE configs[4]; BLOCK then includes the BVH walk
     sc = scenes.add_entities(sc, 100000, seed=11, actor_tris=5000, region=((40, 90, 40), (470, 170, 470)))
+if os.environ.get("CHUNKY_STATS_SCENE") == "indoor":    # BASELINE configs[3]
+    sc = scenes.indoor_room(size=64, width=1920, img_height=1080)
+if os.environ.get("CHUNKY_STATS_SCENE") == "city":      # BASELINE configs[1]
+    from chunkyclplugin_amd import octree2
+    sc = octree2.cached_benchmark_scene(1920, 1080)
 loader = HipSceneLoader(RendererInstance.get(0))
 loader.load_packed(sc)
 r = HipPathTracingRenderer(loader, sc.width, sc.height)
