@@ -50,47 +50,8 @@ DEV unsigned rwalk_record_at(const SceneView& S, int cur) {
 struct WalkWords {
     int4 r0, r1, r2, r3;
 };
-#ifndef CHUNKY_WALK_PAIR_FETCH
-#define CHUNKY_WALK_PAIR_FETCH 0  // tuning builds: 1 = neighbouring lanes fetch each other's records half and half (rwalk_fetch_pairs)
-#endif
-#if CHUNKY_WALK_PAIR_FETCH
-// Experiment (EXPERIMENTS.md 4.8): the four reads of a step, issued so that the two lanes of a pair read 32 CONTIGUOUS bytes of
-// one record in one instruction (one L1 tag look-up per pair instead of one per lane: the walk runs at the L1s' look-up rate) —
-// reads 0 / 1 fetch the even lane's record, the even lane its words 0 and 2, the odd lane words 1 and 3; reads 2 / 3 the odd lane's
-// record the same way — and the halves are then exchanged inside the pair (DPP quad_perm 1,0,3,2).  Every lane ends up with the
-// same four words it used to read by itself.  Called by ALL lanes of the wave (a lane that is not walking still fetches for its
-// partner); `walking` = this lane has a walker.
-DEV int dpp_pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }  // quad_perm [1,0,3,2]
-DEV int dpp_pair_even(int v) { return __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, true); }  // quad_perm [0,0,2,2]
-DEV int dpp_pair_odd(int v) { return __builtin_amdgcn_mov_dpp(v, 0xF5, 0xF, 0xF, true); }   // quad_perm [1,1,3,3]
-DEV int4 dpp_pair_swap4(int4 v) { return make_int4(dpp_pair_swap(v.x), dpp_pair_swap(v.y), dpp_pair_swap(v.z), dpp_pair_swap(v.w)); }
-DEV WalkWords rwalk_fetch_pairs(const SceneView& S, const LaneState& L, bool walking, int lane) {
-    const unsigned at = walking ? rwalk_record_at(S, L.bvh_cur) : 0u;
-    const int odd = lane & 1;
-    const unsigned at_e = (unsigned)dpp_pair_even((int)at), at_o = (unsigned)dpp_pair_odd((int)at);
-    const bool act_e = dpp_pair_even(walking ? 1 : 0) != 0, act_o = dpp_pair_odd(walking ? 1 : 0) != 0;
-    int4 x0 = make_int4(0, 0, 0, 0), x1 = x0, y0 = x0, y1 = x0;
-    if (act_e) {  // the even lane's record: words (0, 1) in one instruction, (2, 3) in the next
-        const int4* __restrict__ p = (const int4*)((const char*)S.bvh_rec + at_e) + odd;
-        x0 = p[0];
-        x1 = p[2];
-    }
-    if (act_o) {  // the odd lane's record
-        const int4* __restrict__ p = (const int4*)((const char*)S.bvh_rec + at_o) + odd;
-        y0 = p[0];
-        y1 = p[2];
-    }
-    // the even lane keeps x (its words 0, 2) and hands over y (the partner's words 0, 2); the odd lane the other way round
-    const int4 send0 = odd ? x0 : y0, send1 = odd ? x1 : y1;
-    const int4 recv0 = dpp_pair_swap4(send0), recv1 = dpp_pair_swap4(send1);
-    WalkWords w;
-    w.r0 = odd ? recv0 : x0;
-    w.r1 = odd ? y0 : recv0;
-    w.r2 = odd ? recv1 : x1;
-    w.r3 = odd ? y1 : recv1;
-    return w;
-}
-#endif
+// (Fetched by pairs of lanes — the two lanes of a pair reading 32 contiguous bytes of one record per instruction and exchanging the
+// halves by DPP, half the L1 tag look-ups — the walk is 9 % SLOWER: EXPERIMENTS.md 4.8.)
 DEV WalkWords rwalk_fetch(const SceneView& S, const LaneState& L) {
     const int4* __restrict__ p = (const int4*)((const char*)S.bvh_rec + rwalk_record_at(S, L.bvh_cur));
     WalkWords w;

@@ -540,14 +540,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                     prof[3] += 1;
                     prof[4] += (unsigned long long)nw;
                 }
-#if CHUNKY_WALK_PAIR_FETCH
-                {
-                    const WalkWords W = rwalk_fetch_pairs(S, L, st == ST_BVH, lane);
-                    if (st == ST_BVH) st = rwalk_apply(S, L, stacks, W);
-                }
-#else
                 if (st == ST_BVH) st = rwalk_step(S, L, stacks);
-#endif
                 nw = count_lanes(st == ST_BVH);
             } while (nw >= stay);
             if (STATS) {
