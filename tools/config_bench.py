@@ -85,6 +85,10 @@ if __name__ == "__main__":
         from chunkyclplugin_amd import octree2
         res.append(run(octree2.cached_benchmark_scene(1920, 1080, entities=True), "configs[1] + the scene's entities (box proxies)",
                        passes=32, launches=2))
+    if "benchmark_entities_cull" in which:
+        from chunkyclplugin_amd import octree2
+        res.append(run(octree2.cached_benchmark_scene(1920, 1080, entities=True), "configs[1] + the scene's entities, CHUNKY_OPT_BVH_CULL_BEHIND (extension)",
+                       passes=32, launches=2, ext={"cull": 1}))
     if "indoor" in which:
         res.append(run(scenes.indoor_room(size=64, width=1920, img_height=1080), "configs[3] (reference light transport)", passes=32))
     if "indoor_nee" in which:
