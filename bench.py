@@ -286,11 +286,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     on_gpu = args.backend == "nccl"
+    rccl_error, ctl = None, None
     if world > 1:
-        if on_gpu:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
+        # CUDA tensors travel over RCCL, CPU tensors over gloo: if the first RCCL collective fails (below), the read-back is staged
+        # through the host instead of losing the whole run
+        dist.init_process_group(args.backend)
+        # the control plane (barriers, timings, rank reports) runs on a gloo group of its own: host-side, no spinning kernel on the
+        # GPUs, and it keeps working when the first RCCL collective fails (below) — the read-back is then staged through the host
+        ctl = dist.new_group(backend="gloo") if on_gpu else None
 
     sc, passes, golden_name, what, e2e_spp = workload(args.config, args)
     if args.passes > 0:
@@ -328,7 +331,7 @@ def main():
         r.sync()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=ctl)
             torch.cuda.synchronize()
 
     reduce_ms = []
@@ -341,14 +344,27 @@ def main():
         t = time.perf_counter()
         if world > 1:
             image.copy_(fb)
-            parallel.reduce_framebuffer(image, dst=0)  # (a gloo rig stages it through the host)
+            parallel.reduce_framebuffer(image, dst=0, group=None if on_gpu else ctl)  # (without a usable RCCL: staged through the host)
             torch.cuda.synchronize()
         elif group_devices:
             r.gather()
         reduce_ms.append((time.perf_counter() - t) * 1e3)
 
     if world > 1:  # the read-back collective once, untimed, on a scratch buffer: communicator and channel set-up are not the path
-        parallel.reduce_framebuffer(torch.zeros_like(fb) if on_gpu else torch.zeros(16), dst=0)
+        if on_gpu:
+            ok = 1
+            try:
+                parallel.reduce_framebuffer(torch.zeros_like(fb), dst=0)
+                torch.cuda.synchronize()
+            except Exception as e:  # e.g. two ranks on one device, IPC refused: say so in the line and stage through the host
+                ok, rccl_error = 0, f"{type(e).__name__}: {str(e)[:300]}"
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)   # every rank takes the same path
+            if int(flag.item()) == 0:
+                on_gpu = False
+                parallel.HOST_STAGING = True
+        if not on_gpu:
+            parallel.reduce_framebuffer(torch.zeros(16), dst=0, group=ctl)
 
     def run_steps(n_steps, first_seed):
         """n_steps steps of `passes` passes, read back + restart of the running mean every MERGE_INTERVAL spp and at the end."""
@@ -377,8 +393,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         dt = float(t.item())
     kernel_ms, launches = r.kernel_time()
     info = r.kernel_info()
@@ -387,7 +403,7 @@ def main():
     devices_seen = [local_rank]
     if world > 1:
         objs = [None] * world
-        dist.all_gather_object(objs, (local_rank, torch.cuda.get_device_name(local_rank), kernel_ms, my_reduce_ms))
+        dist.all_gather_object(objs, (local_rank, torch.cuda.get_device_name(local_rank), kernel_ms, my_reduce_ms), group=ctl)
         devices_seen = [o[0] for o in objs]
         per_rank = {"kernel_ms": [round(float(o[2]), 3) for o in objs], "reduce_ms": [[round(x, 3) for x in o[3]] for o in objs],
                     "device_names": sorted(set(o[1] for o in objs)),
@@ -405,7 +421,7 @@ def main():
         if rank == 0:
             image_check = compare_golden(r.read() if group_devices else image.cpu().numpy(), gold, sc.width)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=ctl)
 
     # ---- scenes with entity BVHs: the same steps once more with CHUNKY_OPT_BVH_CULL_BEHIND (an EXTENSION, default off: children
     #      entirely behind the ray origin count as missed — the reference walks them), reported beside `value`, never as it ----
@@ -421,8 +437,8 @@ def main():
         barrier()
         dt2 = time.perf_counter() - t1
         if world > 1:
-            t = torch.tensor([dt2], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = torch.tensor([dt2], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
             dt2 = float(t.item())
         ms2, n2 = r.kernel_time()
         check2 = None
@@ -441,7 +457,7 @@ def main():
                                    "option those count as missed.  Identical to the reference build's rows here, but not the reference's "
                                    "result by construction (EXPERIMENTS.md 4.4): `value` above is the reference's walk"}
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=ctl)
 
     if rank == 0:
         local_slots = int(parallel.owned_gids(n_pix, 0, args.emulate_world or world, args.tile, sc.width).size)  # pixels rank 0 renders
@@ -504,12 +520,16 @@ def main():
             out["metric"] += f" — EMULATED rank-0 share of a {args.emulate_world}-GPU split on one GPU (not a multi-GPU result)"
         # what the collective actually ran on: the backend and world size torch.distributed reports ("nccl" IS RCCL on ROCm);
         # a single process runs no communicator at all
-        out["rccl_ranks"] = dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0
-        out["collective"] = {"backend": dist.get_backend() if world > 1 else None, "ranks": dist.get_world_size() if world > 1 else 1,
+        backend_used = None if world == 1 else ("nccl" if on_gpu else "gloo")
+        out["rccl_ranks"] = dist.get_world_size() if backend_used == "nccl" else 0
+        out["collective"] = {"backend": backend_used, "ranks": dist.get_world_size() if world > 1 else 1,
                              "devices": sorted(set(devices_seen)) if not group_devices else group_devices,
                              "readback_ms": [round(x, 3) for x in my_reduce_ms],
                              "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                          ("bench.py self-spawn" if "RANK" in os.environ else "none")}
+        if rccl_error or (world > 1 and args.backend == "nccl" and not on_gpu):
+            out["collective"]["rccl_failed"] = rccl_error or "on another rank"
+            out["collective"]["note"] = "the first RCCL collective raised: read-backs were staged through the host and reduced over gloo"
         if group_devices:
             out["group"] = {"members": len(group_devices), "devices": group_devices, "peer_status": inst.peer_status(),
                             "peer_status_legend": "0 local (member 0's device), 1 direct (peer access enabled: xGMI), 2 staged (no peer access), < 0 = -hipError",
@@ -543,7 +563,7 @@ def main():
                 store.wait(["chunky_group_check"], datetime.timedelta(minutes=10))
             except Exception:
                 pass
-        dist.barrier()
+        dist.barrier(group=ctl)
 
     if rank == 0:
         if world == 1 and not args.no_extras and not args.emulate_world:
@@ -581,7 +601,10 @@ def main():
     if group_devices:
         inst.close()
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass  # (a communicator that failed at its first collective may refuse to shut down cleanly)
 
 
 if __name__ == "__main__":

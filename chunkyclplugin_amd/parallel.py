@@ -46,17 +46,21 @@ def owned_gids(n_pixels: int, rank: int, world: int, tile: int = 256, width: int
     return gid[gid < n_pixels].astype(np.int32)
 
 
-def reduce_framebuffer(fb, dst: int = 0):
+HOST_STAGING = False  # set by a caller whose RCCL communicator failed: CUDA tensors are then reduced through the host (gloo)
+
+
+def reduce_framebuffer(fb, dst: int = 0, group=None):
     """The read-back collective: sum the per-rank framebuffers (disjoint tiles, zero elsewhere)
-    onto rank `dst`.  `fb` is a torch tensor (CUDA for RCCL, CPU for gloo); returns it."""
+    onto rank `dst`.  `fb` is a torch tensor (CUDA for RCCL, CPU for gloo); `group` = a gloo group to use when the default
+    group's RCCL communicator is not usable (HOST_STAGING); returns fb."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if fb.is_cuda and dist.get_backend() == "gloo":  # test rigs without RCCL: stage through the host
+        if fb.is_cuda and (HOST_STAGING or dist.get_backend(group) == "gloo"):  # no usable RCCL (test rigs; a failed communicator): through the host
             host = fb.cpu()
-            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
             fb.copy_(host)
         else:
-            dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+            dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return fb
 
 

@@ -32,12 +32,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_bench(world, dump, extra=(), launcher=True, steps=1, passes=PASSES, small=True):
+def _run_bench(world, dump, extra=(), launcher=True, steps=1, passes=PASSES, small=True, backend="gloo"):
     launch = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] if launcher else [sys.executable])
     size = ["--passes", str(passes), "--width", str(W), "--height", str(H), "--chunks", str(CHUNKS)] if small else []
     cmd = [*launch, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "0",
-           *size, "--one-device", "--backend", "gloo", "--no-cpu", "--dump", dump, *extra]
+           *size, "--one-device", "--backend", backend, "--no-cpu", "--dump", dump, *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -164,3 +164,15 @@ def test_other_baseline_configs_through_the_bench(config, kernel):
         assert x["value"] > 1.3 * line["value"] and x["image_check"]["bit_identical"], x
     else:
         assert "extension_behind_cull" not in line
+
+
+def test_a_failing_rccl_communicator_does_not_lose_the_run(tmp_path, single_rank_image):
+    """Failure injection for the first contact with real multi-GPU hardware: two ranks on ONE device with the real backend (nccl =
+    RCCL), which refuses duplicate GPUs at its first collective.  bench.py reports the error in the line, stages the read-backs
+    through the host over its gloo control group, and still delivers the right image."""
+    _sc, want = single_rank_image
+    dump = str(tmp_path / "fb_rccl_fail.npy")
+    line = _run_bench(2, dump, backend="nccl")
+    coll = line["collective"]
+    assert coll["backend"] == "gloo" and line["rccl_ranks"] == 0 and coll["rccl_failed"], coll
+    np.testing.assert_array_equal(np.load(dump).view(np.uint32), want.view(np.uint32))
