@@ -366,14 +366,24 @@ def main():
         if not on_gpu:
             parallel.reduce_framebuffer(torch.zeros(16), dst=0, group=ctl)
 
+    # several GPUs: the steps between two read-backs are handed over in ONE call, so that a share of the image — whose staged
+    # samples fit — runs them as one launch of up to 1024 passes and pays the end-of-launch tail once (the library cuts the call
+    # into launches itself; on one GPU a step stays a call of its own: 256 passes, one launch, as profiled)
+    batch_steps = world > 1 or bool(group_devices) or bool(args.emulate_world)
+
     def run_steps(n_steps, first_seed):
         """n_steps steps of `passes` passes, read back + restart of the running mean every MERGE_INTERVAL spp and at the end."""
-        spp_in_buffer, used, backs = 0, first_seed, 0
-        for k in range(n_steps):
-            r.render_passes(seeds[used:used + passes], first_buffer_spp=spp_in_buffer, sync=False)
-            used += passes
-            spp_in_buffer += passes
-            last = k == n_steps - 1
+        spp_in_buffer, used, backs, k = 0, first_seed, 0, 0
+        while k < n_steps:
+            m = 1
+            if batch_steps:  # as many steps as still fit before the next read-back
+                while k + m < n_steps and spp_in_buffer + m * passes < MERGE_INTERVAL:
+                    m += 1
+            r.render_passes(seeds[used:used + m * passes], first_buffer_spp=spp_in_buffer, sync=False)
+            used += m * passes
+            spp_in_buffer += m * passes
+            k += m
+            last = k == n_steps
             if spp_in_buffer >= MERGE_INTERVAL or last:
                 read_back()
                 backs += 1
@@ -471,7 +481,7 @@ def main():
         launch_ms = kernel_ms / max(launches, 1)
         share = n_pix if group_devices else min(local_slots, n_pix)  # (a group reports its slowest member's kernels for the whole image)
         samples_per_launch = share * args.steps * passes // max(launches, 1)
-        passes_per_launch = min(passes, info["passes_per_launch"])
+        passes_per_launch = args.steps * passes // max(launches, 1)
         bytes_per_sample, n_s, rows, cal = None, 0, [], None
         if not args.no_roofline:
             from oracle import binding
@@ -498,7 +508,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{what}, {sc.width}x{sc.height}, draw-depth 256, {passes} spp per step",
-                       "baseline_config": args.config, "passes_per_step": passes, "spp_timed": args.steps * passes,
+                       "baseline_config": args.config, "passes_per_step": passes, "passes_per_launch": passes_per_launch, "spp_timed": args.steps * passes,
                        "readbacks_timed": readbacks, "merge_interval": MERGE_INTERVAL,
                        "octree_ints": int(sc.octree.size), "octree_depth": int(sc.octree_depth),
                        "entity_bvh_ints": int(len(sc.world_bvh) + len(sc.actor_bvh)),

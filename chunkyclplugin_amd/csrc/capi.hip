@@ -135,6 +135,8 @@ struct chunky_render {
     int timed_launches = 0;
     KernelChoice last_choice{0, 0, 0, 0, -1, 0};  // what the most recent launch ran (chunky_render_kernel_info)
     int launch_cap = 0;  // most passes one launch carries here (staging size); 0 = not determined yet
+    int launch_cap_most = 0;  // ... determined for launches of at most this many passes (kMaxPassesPerLaunch / kMaxPoolPasses)
+    DevBuf seed_buf;      // seeds of a launch longer than the kernel-argument segment holds (render_pool)
     int reserve_passes = 0;  // the pass loop is about to climb to launches of this many passes: size the staging array once
     // on a group: one target per member (this object holds no device data), the caller's share of the image, and the buffers
     // of the read-back exchange: gather_send[i] on member i's device, gather_recv[i] on member 0's
@@ -1335,14 +1337,16 @@ static int collect_timing(chunky_render* r) {
 }
 
 // The most passes one launch of this target carries: render_pool stages every sample of a launch (12 bytes each) — at most
-// kStagingBytes of it, fewer than 2^31 samples, at most kMaxPassesPerLaunch passes.  Sized by the tiles THIS rank renders.
-static int launch_pass_cap(const chunky_render* r, size_t budget) {
+// kStagingBytes of it, fewer than 2^31 samples, at most `most` passes (kMaxPassesPerLaunch: the seeds fit the kernel-argument
+// segment; kMaxPoolPasses for render_pool, which reads longer launches' seeds from device memory — a share of the image on several
+// GPUs then pays the end-of-launch tail once per 1024 passes instead of four times).  Sized by the tiles THIS rank renders.
+static int launch_pass_cap(const chunky_render* r, size_t budget, int most = kMaxPassesPerLaunch) {
     const int64_t n_slots = (int64_t)(staging_floats(r->shard, r->width, r->height, 1) / 3);  // padded tiles
-    if (n_slots <= 0) return kMaxPassesPerLaunch;
+    if (n_slots <= 0) return most;
     int64_t cap = (int64_t)(budget / 12) / n_slots;
     const int64_t cap31 = ((int64_t)1 << 31) / n_slots - 1;
     if (cap > cap31) cap = cap31;
-    if (cap > kMaxPassesPerLaunch) cap = kMaxPassesPerLaunch;
+    if (cap > most) cap = most;
     return cap < 1 ? 1 : (int)cap;
 }
 
@@ -1372,7 +1376,12 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
         r->shard.list = (const int*)r->block_list.p;
         r->shard.n_list = (int)px.size();
     }
-    if (r->launch_cap <= 0) r->launch_cap = launch_pass_cap(r, kStagingBytes);
+    // render_pool takes up to kMaxPoolPasses per launch, the other kernels what the kernel-argument segment holds
+    const int most = pool_kernel_applies(r->kernel_variant, S, r->opts, r->work_counter.p != nullptr) ? kMaxPoolPasses : kMaxPassesPerLaunch;
+    if (r->launch_cap <= 0 || r->launch_cap_most != most) {
+        r->launch_cap = launch_pass_cap(r, kStagingBytes, most);
+        r->launch_cap_most = most;
+    }
     for (int done = 0; done < n;) {
         PassSeeds ps;
         ps.n = (n - done) < r->launch_cap ? (n - done) : r->launch_cap;
@@ -1381,7 +1390,8 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
             HIP_TRY(hipStreamSynchronize(r->ctx->stream));
             r->staging.release();
             // chunky_render_run_ex climbs 1, 8, 64 ... passes per launch: one allocation for where it is going, not four
-            const int ahead = r->reserve_passes < r->launch_cap ? r->reserve_passes : r->launch_cap;
+            int ahead = r->reserve_passes < r->launch_cap ? r->reserve_passes : r->launch_cap;
+            if (ahead > kMaxPassesPerLaunch) ahead = kMaxPassesPerLaunch;  // (the pass loop's own launches stop there)
             if (ahead > ps.n) {
                 const size_t want = staging_floats(r->shard, r->width, r->height, ahead) * sizeof(float);
                 if (hipMalloc(&r->staging.p, want) == hipSuccess) {
@@ -1405,13 +1415,23 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
             r->staging.bytes = need;
         }
         ps.first_spp = first_buffer_spp + done;
-        memcpy(ps.seed, seeds + done, (size_t)ps.n * 4);
+        const int* seeds_dev = nullptr;
+        if (ps.n <= kMaxPassesPerLaunch) {
+            memcpy(ps.seed, seeds + done, (size_t)ps.n * 4);
+        } else {  // a long launch: its seeds go to device memory, in stream order behind the launch that read the buffer last
+            if (!r->seed_buf.p) {
+                HIP_TRY(hipMalloc(&r->seed_buf.p, (size_t)kMaxPoolPasses * 4));
+                r->seed_buf.bytes = (size_t)kMaxPoolPasses * 4;
+            }
+            HIP_TRY(hipMemcpyAsync(r->seed_buf.p, seeds + done, (size_t)ps.n * 4, hipMemcpyHostToDevice, r->ctx->stream));
+            seeds_dev = (const int*)r->seed_buf.p;
+        }
         hipEvent_t e0, e1;
         HIP_TRY(get_event(r, &e0));
         HIP_TRY(get_event(r, &e1));
         HIP_TRY(hipEventRecord(e0, r->ctx->stream));
         HIP_TRY(launch_render(r->kernel_variant, S, r->cam, r->opts, r->shard, ps, r->fb, (int*)r->work_counter.p, r->ctx->stream,
-                              &r->last_choice, (float*)r->staging.p));
+                              &r->last_choice, (float*)r->staging.p, seeds_dev));
         HIP_TRY(hipEventRecord(e1, r->ctx->stream));
         r->pending.emplace_back(e0, e1);
         done += ps.n;
@@ -1529,7 +1549,7 @@ extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]) {
     out8[3] = r->last_choice.blocks;
     out8[4] = r->last_choice.pool;
     out8[5] = r->last_choice.ext;
-    out8[6] = r->launch_cap > 0 ? r->launch_cap : launch_pass_cap(r, kStagingBytes);
+    out8[6] = r->launch_cap > 0 ? r->launch_cap : launch_pass_cap(r, kStagingBytes);  // (of the kernel family that ran last)
     return CHUNKY_OK;
 }
 

@@ -40,6 +40,9 @@ struct HitRecord {
 // scalar loads, no per-launch host->device copy): pass k uses seed[k] and bufferSpp first_spp + k
 // (OpenClPathTracingRenderer.java:106-109).
 constexpr int kMaxPassesPerLaunch = 256;  // seeds travel in the kernel-argument segment (4 KB in all); the pass index is 8 bits
+// render_pool takes longer launches when the staged samples fit (a share of the image on several GPUs: fewer end-of-launch tails):
+// the seeds then travel in device memory (launch_render's seeds_dev)
+constexpr int kMaxPoolPasses = 1024;
 struct PassSeeds {
     int n, first_spp;
     int seed[kMaxPassesPerLaunch];
@@ -86,9 +89,10 @@ inline hipError_t current_device_cus(int* n_cu) {
 }
 // true when launch_render will run render_pool for this scene / option set (else launch_fallback: render_waves, render_lanes)
 bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, bool have_queue_and_staging);
+// P.n <= kMaxPassesPerLaunch with the seeds in P.seed, or (render_pool only) up to kMaxPoolPasses with the seeds in seeds_dev
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream,
-                         KernelChoice* chosen = nullptr, float* staging = nullptr);
+                         KernelChoice* chosen = nullptr, float* staging = nullptr, const int* seeds_dev = nullptr);
 // the kernels behind render_pool (render_fallback.hip): render_waves, render_lanes
 hipError_t launch_fallback(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                            const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen);

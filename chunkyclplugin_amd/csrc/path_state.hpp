@@ -474,6 +474,7 @@ struct WaveArgs {
     unsigned xcd_stripe;   // render_pool: samples per range (xcd_claim): the tiles over kXcdRanges, rounded up, x P.n x kSampleTile
     FastDiv div_sub;       // render_pool: division of a sample index by P.n x kSubBlock (the samples of one sub-block)
     FastDiv div_bw;        // render_pool: division of a tile index by the tiles per image row
+    const int* seeds_dev;  // render_pool: the launch's seeds in device memory when it carries more passes than P.seed holds, else null
 };
 static_assert(sizeof(WaveArgs) <= 4096, "launch arguments must fit the 4 KB kernel-argument segment");
 typedef const WaveArgs __attribute__((address_space(4))) * WaveArgPtr;

@@ -596,7 +596,8 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                     const SlotPixel px = pool_slot_pixel(T, C.width, C.height, slot, arg_copy(&A->div_bw));
                     const int gid = px.gid;
                     if (gid < C.width * C.height) {  // else: a padding slot, nothing to render (the lane claims again)
-                        unsigned rng = (unsigned)A->P.seed[pass] + (unsigned)gid;
+                        const int* seeds_dev = A->seeds_dev;  // (wave-uniform: launches longer than P.seed holds)
+                        unsigned rng = (unsigned)(seeds_dev ? seeds_dev[pass] : A->P.seed[pass]) + (unsigned)gid;
                         rt_pcg_next(&rng);
                         const RayOD pr = primary_ray(C, gid, rng, false, px.x, px.y);
                         L.sidx = (int)sidx;
@@ -691,7 +692,7 @@ __global__ void __launch_bounds__(256) gather_kernel(ShardView T, int width, int
 // the generic tree form only).
 static hipError_t launch_pool(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                               const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
-                              float* staging) {
+                              float* staging, const int* seeds_dev) {
     const int block = 256;
     int n_cu = 0;
     if (hipError_t e = current_device_cus(&n_cu)) return e;
@@ -768,7 +769,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     if (e != hipSuccess) return e;
     WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)depth, staging, (unsigned)n_samples,
                (unsigned)((n_tiles + kXcdRanges - 1) / kXcdRanges * kSampleTile * P.n), fast_div((unsigned)P.n * (unsigned)kSubBlock),
-               fast_div((unsigned)((C.width + kTileEdge - 1) >> kTileLog))};
+               fast_div((unsigned)((C.width + kTileEdge - 1) >> kTileLog)), seeds_dev};
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -787,9 +788,12 @@ bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, b
 }
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
-                         float* staging) {
-    if (pool_kernel_applies(variant, S, O, work_counter && staging))
-        return launch_pool(variant, S, C, O, T, P, res, work_counter, stream, chosen, staging);
+                         float* staging, const int* seeds_dev) {
+    if (pool_kernel_applies(variant, S, O, work_counter && staging)) {
+        if (P.n > kMaxPoolPasses || (P.n > kMaxPassesPerLaunch && !seeds_dev)) return hipErrorInvalidValue;
+        return launch_pool(variant, S, C, O, T, P, res, work_counter, stream, chosen, staging, P.n > kMaxPassesPerLaunch ? seeds_dev : nullptr);
+    }
+    if (P.n > kMaxPassesPerLaunch) return hipErrorInvalidValue;
     if (T.world != 1 && T.tile == 0) {
         // shards of 16 x 16 blocks are mapped by render_pool only: the other kernels take the rank's pixels as a list
         if (!T.list) return hipErrorNotSupported;

@@ -13,7 +13,7 @@
 
 // the kernel launchers live in the other translation units; nothing under test reaches them
 namespace chunky {
-hipError_t launch_render(int, const SceneView&, const CameraView&, const RenderOpts&, const ShardView&, const PassSeeds&, float*, int*, hipStream_t, KernelChoice*, float*) { return hipErrorNotSupported; }
+hipError_t launch_render(int, const SceneView&, const CameraView&, const RenderOpts&, const ShardView&, const PassSeeds&, float*, int*, hipStream_t, KernelChoice*, float*, const int*) { return hipErrorNotSupported; }
 bool pool_kernel_applies(int, const SceneView&, const RenderOpts&, bool) { return false; }
 hipError_t launch_gather(bool, const ShardView&, int, int, float*, float*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_trace_records(int, const SceneView&, const CameraView&, const RenderOpts&, int, const int*, int, HitRecord*, int*, float*, hipStream_t) { return hipErrorNotSupported; }

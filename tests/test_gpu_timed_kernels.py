@@ -139,6 +139,42 @@ def test_outdoor_block_shards(gpu_instance, port, outdoor, world, rank, passes):
     loader.close()
 
 
+@pytest.mark.parametrize("world,rank,passes,cap", [(8, 3, 700, 1024), (1, 0, 300, 342), (2, 1, 600, 685)])
+def test_launches_longer_than_the_argument_segment(gpu_instance, port, outdoor, world, rank, passes, cap):
+    """render_pool carries up to 1024 passes per launch when the staged samples fit 8 GiB (a share of the image on several GPUs
+    pays the end-of-launch tail once instead of four times); beyond 256 passes the seeds travel in device memory.  One call of
+    `passes` passes is then ONE launch, and the image is the oracle's."""
+    sc = outdoor
+    seeds = native.java_random_ints(passes)
+    loader, r = make(gpu_instance, sc)
+    r.set_shard(rank, world, 0)
+    r.kernel_time()
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert (info["tree"], info["pool"], info["passes_per_launch"]) == (17, 56, cap), info
+    assert r.kernel_time()[1] == 1                                    # one launch
+    own = parallel.owned_gids(sc.width * sc.height, rank, world, 0, sc.width)
+    mine = np.intersect1d(row_gids(sc, (411, 1003))[::3], own)
+    compare_rows(r, port, sc, seeds, mine, f"{passes} passes in one launch, share {rank}/{world}")
+    # a second long launch continues the running mean (and reuses the seed buffer behind the first)
+    more = native.java_random_ints(passes + 290)[passes:]
+    r.render_passes(more, first_buffer_spp=passes)
+    g = mine[::7]
+    got = r.read().reshape(-1, 3)[g]
+    want = port.render_gids(sc, seeds, g, threads=THREADS)
+    want = port.render_gids(sc, more, g, first_spp=passes, res=want, threads=THREADS).reshape(-1, 3)[g]
+    np.testing.assert_array_equal(bits(got), bits(want))
+    # the fallback kernels keep to what the argument segment holds
+    r.set_option(native.OPT_KERNEL, 8)
+    r.reset()
+    r.kernel_time()
+    r.render_passes(seeds[:300])
+    assert r.kernel_info()["pool"] < 0 and r.kernel_info()["passes_per_launch"] == 256 and r.kernel_time()[1] == 2
+    compare_rows(r, port, sc, seeds[:300], mine[::5], "300 passes, round 1's kernel: two launches")
+    r.close()
+    loader.close()
+
+
 def test_city_kernel(gpu_instance, port):
     """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_pool<18, 56>."""
     from chunkyclplugin_amd import octree2
