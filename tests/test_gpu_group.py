@@ -215,3 +215,17 @@ def test_group_peer_status(group3, gpu_instance):
     import ctypes as C
     out = (C.c_int * 2)()
     assert native.lib().chunky_group_peer_status(group3._h, out, 2) == native.E_INVALID  # room for fewer members than the group has
+
+
+def test_group_long_launches(group3, port):
+    """More passes in one call than the kernel-argument segment holds seeds for: every member runs them as one launch with its
+    seeds in device memory (its own buffer on its own device), and the gathered image is the oracle's."""
+    sc = scenes.outdoor_world(chunks=4, height=64, seed=31, width=200, img_height=120, aabb_frac=0.05, quad_frac=0.03)
+    seeds = native.java_random_ints(700)
+    lg, rg = renderer_on(group3, sc)
+    rg.kernel_time()
+    rg.render_passes(seeds)
+    assert rg.kernel_info()["passes_per_launch"] == 1024 and rg.kernel_time()[1] == 1
+    np.testing.assert_array_equal(bits(rg.read()), bits(port.render_passes(sc, seeds, threads=binding.usable_threads())))
+    rg.close()
+    lg.close()
