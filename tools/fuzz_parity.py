@@ -48,6 +48,8 @@ def main():
                 ext["bsdf"] = 1
         variant = 0 if ext else int(rng.choice(VARIANTS))
         passes = int(rng.choice([1, 2, 3, 7, 16, 33, 70]))
+        if w * h < 2000 and rng.random() < 0.08:
+            passes = int(rng.choice([257, 300, 700, 1024, 1100]))  # launches longer than the argument segment holds seeds for (pool kernel), or cut in several
         first = int(rng.choice([0, 0, 5, 1000]))
         draw, depth, scale = int(rng.choice([256, 256, 40, 3])), int(rng.choice([5, 5, 1, 2, 9])), float(rng.choice([13.0, 13.0, 0.0, 2.5]))
         world = int(rng.choice([1, 1, 2, 3, 8]))
