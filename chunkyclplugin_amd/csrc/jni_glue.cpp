@@ -197,6 +197,9 @@ JNIEXPORT jlong JNICALL J(renderCreate)(JNIEnv* env, jclass, jlong ctx, jlong sc
     return (jlong)r;
 }
 JNIEXPORT void JNICALL J(renderDestroy)(JNIEnv* env, jclass, jlong r) { CHECK(chunky_render_destroy((chunky_render*)r)); }
+JNIEXPORT void JNICALL J(renderSetOption)(JNIEnv* env, jclass, jlong r, jint option, jint value) {
+    CHECK(chunky_render_set_option((chunky_render*)r, option, value));
+}
 JNIEXPORT void JNICALL J(renderSetCamera)(JNIEnv* env, jclass, jlong r, jint type, jfloatArray settings) {
     if (bad_length(env, settings, 15, "renderSetCamera")) return;  // the C side checks the exact count for the projector
     jfloat* p = env->GetFloatArrayElements(settings, nullptr);

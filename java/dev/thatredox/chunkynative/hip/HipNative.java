@@ -45,6 +45,9 @@ public final class HipNative {
     public static native long renderCreate(long ctx, long scene, int width, int height);
     public static native void renderDestroy(long render);
     public static native void renderSetCamera(long render, int projectorType, float[] settings);
+    /** chunky_render_set_option: the render-loop constants of the reference kernel (OPT_DRAW_DEPTH 256, OPT_MAX_DEPTH 5) and
+     *  the extensions, all of which default to the reference's behaviour (include/chunky_hip.h). */
+    public static native void renderSetOption(long render, int option, int value);
     public static native void renderPasses(long render, int[] seeds, int firstBufferSpp);
     public static native void renderRead(long render, float[] out);
     /** chunky_render_preview; width/height are the render target's, the glue checks argbOut against them. */
@@ -83,4 +86,6 @@ public final class HipNative {
     public static final int PALETTE_BLOCK = 0, PALETTE_MATERIAL = 1, PALETTE_AABB = 2, PALETTE_QUAD = 3, PALETTE_TRIG = 4;
     public static final int BVH_WORLD = 0, BVH_ACTOR = 1;
     public static final int PEER_LOCAL = 0, PEER_DIRECT = 1, PEER_STAGED = 2;
+    public static final int OPT_DRAW_DEPTH = 0, OPT_MAX_DEPTH = 1, OPT_EMITTER_SCALE = 2, OPT_KERNEL = 3, OPT_SUN_SAMPLING = 4,
+            OPT_EMITTERS = 5, OPT_BSDF = 6, OPT_EMITTER_NEE = 7, OPT_BVH_CULL_BEHIND = 8;
 }
