@@ -469,6 +469,37 @@ def main():
         if world > 1:
             dist.barrier(group=ctl)
 
+    # ---- configs[3] is stated with "NEE on": the reference kernel has no emitter sampling, so the same steps run once more with
+    #      CHUNKY_OPT_EMITTER_NEE (an EXTENSION specified by oracle/port.c) and are reported beside `value` ----
+    emitter_nee = None
+    if args.config == 3 and not args.no_extras and not args.emulate_world and args.kernel == 0:
+        r.set_option(native.OPT_EMITTER_NEE, 1)
+        r.reset()
+        run_steps(1, 0)          # the extended instantiation's first launch (its staging array, its emitter list) is not timed
+        r.reset()
+        barrier()
+        r.kernel_time()
+        reduce_ms.clear()
+        t1 = time.perf_counter()
+        run_steps(args.steps, args.warmup * passes)
+        barrier()
+        dt3 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt3], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+            dt3 = float(t.item())
+        ms3, n3 = r.kernel_time()
+        info3 = r.kernel_info()
+        r.set_option(native.OPT_EMITTER_NEE, 0)
+        if rank == 0:
+            emitter_nee = {"option": "CHUNKY_OPT_EMITTER_NEE = 1 (extension, default 0; include/chunky_hip.h)",
+                           "value": round(n_pix * args.steps * passes / dt3 / 1e6, 3), "unit": "Msamples/s",
+                           "launch_ms": round(ms3 / max(n3, 1), 4), "kernel": "render_pool<%d,%d,ext>+fold_kernel" % (info3["tree"], info3["pool"]),
+                           "note": "one emitter block, face and point sampled per diffuse vertex plus its shadow ray (two more traces per vertex); "
+                                   "no reference implementation exists, parity is against its own specification (tests/test_gpu_extensions.py)"}
+        if world > 1:
+            dist.barrier(group=ctl)
+
     if rank == 0:
         local_slots = int(parallel.owned_gids(n_pix, 0, args.emulate_world or world, args.tile, sc.width).size)  # pixels rank 0 renders
         # an emulated share renders only rank 0's tiles: count what was rendered, and say so
@@ -550,6 +581,8 @@ def main():
             out["image_check"] = image_check
         if behind_cull is not None:
             out["extension_behind_cull"] = behind_cull
+        if emitter_nee is not None:
+            out["extension_emitter_nee"] = emitter_nee
 
     # ---- N > 1: rank 0 alone opens all GPUs behind one context — the in-process path a JVM binds (the others wait) ----------
     if world > 1 and not args.no_extras:

@@ -159,6 +159,9 @@ def test_other_baseline_configs_through_the_bench(config, kernel):
     assert line["config"]["baseline_config"] == config and line["roofline"]["kernel"] == kernel, line["roofline"]
     assert line["image_check"]["bit_identical"], line["image_check"]
     assert line["end_to_end"]["value"] > 0 and line["roofline"]["frac"] > 0 and line["value"] > 0
+    if config == 3:  # stated with "NEE on": the emitter-sampling extension is reported beside the reference's light transport
+        x = line["extension_emitter_nee"]
+        assert 0 < x["value"] < line["value"] and x["kernel"].startswith("render_pool<17,32,ext>"), x
     if config == 4:  # scenes with entities also report the behind-the-ray cull (an extension) beside the reference's walk
         x = line["extension_behind_cull"]
         assert x["value"] > 1.3 * line["value"] and x["image_check"]["bit_identical"], x
