@@ -639,10 +639,13 @@ def main():
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
 
-    r.close()
-    loader.close()
-    if group_devices:
-        inst.close()
+    try:  # the line is out: a hiccup while tearing down must not turn a measured run into a failed one
+        r.close()
+        loader.close()
+        if group_devices:
+            inst.close()
+    except Exception as e:
+        print(f"bench.py: teardown: {e}", file=sys.stderr)
     if world > 1:
         try:
             dist.destroy_process_group()
