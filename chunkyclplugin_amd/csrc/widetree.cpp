@@ -1,6 +1,7 @@
 // widetree.cpp — see widetree.hpp
 #include "widetree.hpp"
 
+#include <cstdlib>
 #include <deque>
 
 namespace chunky {
@@ -10,7 +11,12 @@ int default_wide_levels(int depth, int* level_bits) {
     // top two or three octree-node fetches of a lookup become one array read, and the kernels keep
     // compile-time shifts for the levels below
     if (depth < 0) depth = 0;
-    int n3 = depth <= 6 ? 0 : (depth - 6 + 2) / 3;
+    int most_top = 6;
+    if (const char* e = getenv("CHUNKY_WIDE_TOP_BITS")) {  // tuning runs: a larger dense top (7: 128^3 entries = 8 MiB) for one level less
+        const int v = atoi(e);
+        if (v >= 4 && v <= 8) most_top = v;
+    }
+    int n3 = depth <= most_top ? 0 : (depth - most_top + 2) / 3;
     if (n3 > kWideMaxLevels - 1) n3 = kWideMaxLevels - 1;
     level_bits[0] = depth - 3 * n3;
     for (int i = 1; i <= n3; i++) level_bits[i] = 3;

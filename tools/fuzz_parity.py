@@ -96,6 +96,8 @@ def main():
                   f"draw={draw} depth={depth} scale={scale} shard={rank}/{world}/{tile} group={on_group} ext={ext} layout={layout} cull={cull} kernel={r.kernel_info()} ndiff={diff.size} first_diff={diff[:4]}", flush=True)
         r.close()
         loader.close()
+        if (it + 1) % 2000 == 0:
+            print(f"fuzz: {it + 1} of {n_iter} configurations from seed {seed0} so far, {bad} differed", flush=True)
     print(f"fuzz: {n_iter} configurations from seed {seed0}, {bad} differed")
     sys.exit(1 if bad else 0)
 
