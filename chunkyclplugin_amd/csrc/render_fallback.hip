@@ -203,13 +203,16 @@ DEV int next_sample_single(const SceneView& S, const CameraView& C, const ShardV
         float fs = (float)spp, fs1 = (float)(spp + 1);
         L.mean = f3{(L.mean.x * fs + L.radiance.x) / fs1, (L.mean.y * fs + L.radiance.y) / fs1,
                     (L.mean.z * fs + L.radiance.z) / fs1};
-        L.pass += 1;
-        if (L.pass >= n_passes) {
+        // (L.pass is an 8-bit field: compare before counting, a launch of 256 passes ends at index 255 — counting first wrapped it to 0
+        // and the pixel never ended: found by the fuzz of round 4, which was the first to give this kernel 256 passes per launch)
+        if ((int)L.pass + 1 >= n_passes) {
             float* px = res + 3 * (size_t)L.gid;
             px[0] = L.mean.x;
             px[1] = L.mean.y;
             px[2] = L.mean.z;
             need_pixel = true;
+        } else {
+            L.pass += 1;
         }
     }
     const int slot = claim_slot<kPixelBatch>(Q, pool, need_pixel);  // convergent: every lane of the wave is here

@@ -501,3 +501,21 @@ def test_entity_bvh_record_placement_is_invisible(gpu_instance, layout, monkeypa
         np.testing.assert_array_equal(rec[i, :n]["distance"].view(np.uint32), g["records"][i, :n]["distance"].view(np.uint32))
     r.close()
     loader.close()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("variant", [24, 8, 40, 2])
+def test_fallback_kernels_at_256_passes_per_launch(gpu_instance, port, variant):
+    """The most passes a launch of the fallback kernels carries.  render_waves with one lane per pixel (variant 8 | 16) keeps the
+    pass index in an 8-bit field and used to count before comparing: at exactly 256 passes the index wrapped and the launch
+    never ended (found by the fuzz of round 4).  256 and 300 passes (two launches) against the oracle."""
+    sc = scenes.tiny_scene(seed=5, size=32, width=64, height=30, entities=24)
+    loader, r = make_renderer(gpu_instance, sc, variant)
+    for passes in (256, 300):
+        seeds = scenes.java_random_ints(passes)
+        r.reset()
+        r.render_passes(seeds)
+        assert r.kernel_info()["pool"] < 0
+        assert_radiance(r.read(), port.render_passes(sc, seeds), f"variant {variant}, {passes} passes")
+    r.close()
+    loader.close()

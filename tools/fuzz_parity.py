@@ -67,6 +67,10 @@ def main():
         layout = str(rng.choice(["0,0", "0,0", "3,4", "64,8", "4096,32"]))
         os.environ["CHUNKY_BVH_LAYOUT"] = layout
         cull = int(ents > 0 and rng.random() < 0.3)
+        if os.environ.get("FUZZ_VERBOSE"):
+            import time
+            print(f"it={it} view={w}x{h} ents={ents} variant={variant} passes={passes} first={first} draw={draw} depth={depth} shard={rank}/{world}/{tile} "
+                  f"group={on_group} ext={ext} layout={layout} cull={cull} t={time.time():.2f}", flush=True)
         loader = HipSceneLoader(groups[on_group] if on_group else inst)
         loader.load_packed(sc)
         r = HipPathTracingRenderer(loader, w, h)
