@@ -7,9 +7,11 @@
 namespace chunky {
 
 int default_wide_levels(int depth, int* level_bits) {
-    // one dense top node of 4..6 bits per axis (at most 64^3 entries = 1 MiB) over levels of 3 bits: the
-    // top two or three octree-node fetches of a lookup become one array read, and the kernels keep
-    // compile-time shifts for the levels below
+    // one dense top node of 4..7 bits per axis over levels of 3 bits: the top octree-node fetches of a lookup become one array
+    // read, and the kernels keep compile-time shifts for the levels below.  The top holds at most 64^3 entries (1 MiB) — except
+    // that a 4-bit top over two or more levels gives one of them up and becomes a 7-bit top (128^3 entries, 8 MiB): a depth-10
+    // world is then two dependent reads per lookup instead of three (the reference's benchmark city: 5153 -> 5424 Msamples/s;
+    // a depth-7 world as ONE 128^3 node measured 8 % slower than 4 + 3 and keeps its level)
     if (depth < 0) depth = 0;
     int most_top = 6;
     if (const char* e = getenv("CHUNKY_WIDE_TOP_BITS")) {  // tuning runs: a larger dense top (7: 128^3 entries = 8 MiB) for one level less
@@ -18,6 +20,7 @@ int default_wide_levels(int depth, int* level_bits) {
     }
     int n3 = depth <= most_top ? 0 : (depth - most_top + 2) / 3;
     if (n3 > kWideMaxLevels - 1) n3 = kWideMaxLevels - 1;
+    if (!getenv("CHUNKY_WIDE_TOP_BITS") && n3 >= 2 && depth - 3 * n3 == 4) n3 -= 1;
     level_bits[0] = depth - 3 * n3;
     for (int i = 1; i <= n3; i++) level_bits[i] = 3;
     return n3 + 1;

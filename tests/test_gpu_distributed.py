@@ -152,7 +152,7 @@ def test_group_mode_of_the_bench():
     assert e["readbacks"] == 1 and e["value"] > 0 and e["cold_value"] > 0 and e["finite"], e
 
 
-@pytest.mark.parametrize("config,kernel", [(1, "render_pool<18,56>+fold_kernel"), (3, "render_pool<17,56>+fold_kernel"), (4, "render_pool<17,16,bvh>+fold_kernel")])
+@pytest.mark.parametrize("config,kernel", [(1, "render_pool<17,56>+fold_kernel"), (3, "render_pool<17,56>+fold_kernel"), (4, "render_pool<17,16,bvh>+fold_kernel")])
 def test_other_baseline_configs_through_the_bench(config, kernel):
     """`bench.py --config n`: the other BASELINE configurations with the same JSON schema, each checking its own image."""
     line = _run_single(["--config", str(config)])

@@ -56,7 +56,7 @@ def test_reference_still_gives_the_committed_rows(ref, views):
 
 
 # (tree form, entity-BVH phases) of the instantiation bench.py / tools/config_bench.py time on each view
-TIMED_KERNEL = {"city": (18, False), "city_entities": (18, True), "outdoor": (17, False), "indoor": (17, False),
+TIMED_KERNEL = {"city": (17, False), "city_entities": (17, True), "outdoor": (17, False), "indoor": (17, False),
                 "entities": (17, True), "entities4k": (17, True)}
 
 
