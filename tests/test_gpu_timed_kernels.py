@@ -198,7 +198,7 @@ def test_city_kernel(gpu_instance, port):
 
 def test_city_with_its_entities(gpu_instance, port):
     """configs[1] with the scene's own 4 188 entities and 389 actors (box proxies, octree2.with_entities) in the world and
-    actor BVHs: render_pool<18, ., bvh> on the depth-10 octree, whole rows against the oracle; and a close-up view in
+    actor BVHs: render_pool<17, ., bvh> on the depth-10 octree, whole rows against the oracle; and a close-up view in
     which the entities fill the picture."""
     from chunkyclplugin_amd import octree2
     sc = octree2.cached_benchmark_scene(1920, 1080, entities=True)
