@@ -13,6 +13,19 @@ int default_wide_levels(int depth, int* level_bits) {
     // world is then two dependent reads per lookup instead of three (the reference's benchmark city: 5153 -> 5424 Msamples/s;
     // a depth-7 world as ONE 128^3 node measured 8 % slower than 4 + 3 and keeps its level)
     if (depth < 0) depth = 0;
+    if (const char* e = getenv("CHUNKY_WIDE_LEVELS")) {  // tuning runs: an explicit split "top,l1,l2,..." (runs the generic tree form)
+        int b[kWideMaxLevels], n = 0, sum = 0;
+        for (const char* p = e; *p && n < kWideMaxLevels;) {
+            b[n] = atoi(p);
+            sum += b[n++];
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        if (n >= 1 && sum == depth) {
+            for (int i = 0; i < n; i++) level_bits[i] = b[i];
+            return n;
+        }
+    }
     int most_top = 6;
     if (const char* e = getenv("CHUNKY_WIDE_TOP_BITS")) {  // tuning runs: a larger dense top (7: 128^3 entries = 8 MiB) for one level less
         const int v = atoi(e);
