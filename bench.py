@@ -637,6 +637,15 @@ def main():
                                    "scaling": "profiles/r04_cpu_sweep.jsonl (1 ... 256 threads on this box type: 0.86 of linear at 8 threads, "
                                               "flat from the quota on, slower beyond it)"}
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            # Chunky's own Java PathTracingRenderer (se.llbit:chunky-core) is timed only where a JDK and a
+            # Chunky jar exist on the box; say which it is instead of leaving the question open
+            import glob
+            import shutil
+            jars = [p for pat in ("/usr/share/java/chunky*.jar", os.path.expanduser("~/.chunky/lib/chunky-core*.jar"), os.path.join(ROOT, "chunky-core*.jar"))
+                    for p in glob.glob(pat)]
+            out["cpu_baseline"]["chunky_java_renderer"] = (
+                "unavailable: " + ("no JDK (`java` not on PATH)" if not shutil.which("java") else "a JDK but no chunky-core jar") + " on this box"
+                if not (shutil.which("java") and jars) else f"found {jars[0]} (not driven by this bench)")
         print(json.dumps(out), flush=True)
 
     try:  # the line is out: a hiccup while tearing down must not turn a measured run into a failed one
