@@ -16,11 +16,13 @@ Workloads (`--config`, named in config.workload):
 Scene upload is outside the timed region; the framebuffer lives in HBM.
 
 The timed region follows the reference's loop (OpenClPathTracingRenderer.java:95-184): passes accumulate as a float running
-mean; every 1024 spp (its merge interval) the buffer is read back and the mean starts again from zero.  At N = 1 the
-read-back itself is NOT in `value` (inputs and outputs stay in HBM, as the contract says) — `end_to_end` below times it.
+mean; every 1024 spp (its merge interval) the buffer is read back and the mean starts again from zero.  A read-back is the
+SAME at every N, so that a scaling curve divides like by like: whatever exchange assembles the image on rank 0 / member 0
+(N = 1: none; N > 1: ONE RCCL reduce of the per-rank framebuffers; --group: the library's one RCCL exchange), then rank 0
+copies the image into pinned host memory (the reference's clEnqueueReadBuffer, :164-166) — all inside the timed region and
+inside `value`; `value_hbm_resident` is the same samples over the timed region minus the read-backs (nothing leaves HBM).
 N > 1: one process per GPU, the scene replicated, the image cut into 16x16-pixel blocks dealt round-robin
-(chunky_render_set_shard), no collective on the data path, ONE RCCL reduce of the per-rank framebuffers to rank 0 per
-read-back (every 1024 spp and at the end), inside the timed region.  Total work is fixed as N grows => "scaling": "strong".
+(chunky_render_set_shard), no collective on the data path.  Total work is fixed as N grows => "scaling": "strong".
 
 The JSON line also carries:
   roofline     — the contract figure: achieved = ALGORITHMIC bytes per sample of the reference's
@@ -30,6 +32,9 @@ The JSON line also carries:
                  (PMC FETCH_SIZE x2 + WRITE_SIZE per launch), `valu` and `limits` (VALU lane fraction, L1 tag look-ups per
                  cycle, L2 request bandwidth, wait share: the real limiter) come from the committed PMC summary named in
                  `pmc_source` and are attached only when it was collected for the kernel / launch shape of this run.
+  other_configs — N = 1, default configuration only: short warm legs (3 steps) of BASELINE configs[1], [3], [4] on the same
+                 box in the same run, each with value, launch_ms, image_check against the reference's rows and the contract
+                 roofline, so that the driver's record carries every configuration, not only the headline.
   end_to_end   — N = 1 (and --group): the same spp through chunky_render_run_ex with merge interval 1024 — the reference's
                  whole loop incl. the climb to full-size launches, every read-back into host memory and the double-precision
                  merge into Chunky's sample buffer — cold (first run on a fresh target) and warm (second run).
@@ -201,6 +206,105 @@ def end_to_end_leg(loader, sc, spp, make_renderer):
     return out
 
 
+def kernel_label(info):
+    bvh_tag = ",bvh" if info["bvh"] else ""
+    return ("render_pool<%d,%d%s>+fold_kernel" % (info["tree"], info["pool"], bvh_tag) if info["pool"] >= 0 else
+            "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh"))
+
+
+def nearest_ceiling(pm, physical_frac):
+    """Which hardware resource the kernel sits closest to, from the committed PMC entry of this launch shape: the largest
+    used / available fraction among VALU issue slots, L1 tag look-ups, the scalar pipe, L2 requests and physical HBM bytes."""
+    if not pm:
+        return None
+    lim = pm.get("limits", {})
+    cand = {"valu_issue": lim.get("valu_issue_frac"), "l1_tag_lookups": lim.get("l1_tag_lookups_per_cycle"),
+            "scalar_pipe": lim.get("scalar_pipe_frac"), "l2_requests": lim.get("l2_request_frac_of_34.5TBps"), "hbm_physical": physical_frac}
+    cand = {k: float(v) for k, v in cand.items() if v is not None}
+    if not cand:
+        return None
+    best = max(cand, key=cand.get)
+    return {"resource": best, "frac": round(cand[best], 4), "all": {k: round(v, 4) for k, v in sorted(cand.items(), key=lambda kv: -kv[1])},
+            "note": "used / available per resource over the launch (profiles/pmc_traffic.json); valu_issue counts issue slots, not useful "
+                    "lanes (x valu_lane_util for those); the contract `frac` above is a work-rate convention, this is the hardware view"}
+
+
+def roofline_object(sc, config, info, launch_ms, launches, samples_per_launch, passes_per_launch, seeds, threads, n_rows, kernel_variant,
+                    attach_pmc=True, build_oracle=True):
+    """The contract roofline of one measured leg + what the committed PMC entry of this launch shape says."""
+    from oracle import binding
+    binding.port(build=build_oracle)
+    rows = sample_rows(sc.height, n_rows)
+    n_s, cal_dt, ctr = oracle_row_sample(sc, seeds[:1], rows, threads, count=True, pin=True)
+    bytes_per_sample = binding.algorithmic_bytes(ctr)
+    achieved = bytes_per_sample * samples_per_launch / (launch_ms * 1e-3) / 1e9 if (launch_ms > 0 and bytes_per_sample) else 0.0
+    pm = pmc_entry(config, info, passes_per_launch, samples_per_launch, kernel_variant) if attach_pmc else None
+    traffic = pm.get("hbm_bytes_per_launch") if pm else None
+    physical = traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and launch_ms > 0 else None
+    frac = achieved / HBM_PEAK_GBS
+    roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(frac, 5), "traffic": traffic,
+            "achieved_is": "algorithmic bytes of the reference access stream / launch time (SURVEY 8d), "
+                           "not physical HBM traffic: the scene is cache-resident",
+            "frac_above_one": bool(frac > 1.0),
+            "physical_frac": round(physical, 5) if physical is not None else None,
+            "nearest_ceiling": nearest_ceiling(pm, physical),
+            "valu": pm.get("valu") if pm else None, "limits": pm.get("limits") if pm else None,
+            "pmc_source": pm.get("source") if pm else None, "pmc_collected": pm.get("collected") if pm else None,
+            "algorithmic_bytes_per_sample": round(bytes_per_sample, 1) if bytes_per_sample else None,
+            "kernel": kernel_label(info), "launches": launches, "launch_ms": round(launch_ms, 4),
+            "samples_per_launch": samples_per_launch,
+            "counted_on": f"{n_s} samples ({len(rows)} rows of this view, seed 0)"}
+    if frac > 1.0:
+        roof["frac_note"] = ("above 1: the counted bytes are the REFERENCE's access stream (a root restart per march step); this kernel makes two "
+                             "tree reads per step from cache, so it does not perform the counted accesses — see nearest_ceiling for what binds")
+    return roof, n_s / max(cal_dt, 1e-6), rows
+
+
+def other_config_leg(inst, config, args, threads, steps=3):
+    """One of BASELINE configs[1], [3], [4] on this GPU, warm: `steps` steps of its own passes per step (one launch each), the
+    launch time from HIP events, the image check against the reference's rows and the contract roofline."""
+    from chunkyclplugin_amd import native
+    from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
+    t_leg = time.perf_counter()
+    sc, passes, golden_name, what, _ = workload(config, args)
+    n_pix = sc.width * sc.height
+    loader = HipSceneLoader(inst)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, sc.width, sc.height)
+    try:
+        r.set_camera(sc.projector_type, sc.camera)
+        r.set_option(native.OPT_KERNEL, args.kernel)
+        seeds = native.java_random_ints((steps + 1) * passes)
+        r.render_passes(seeds[:passes])          # warm-up at the timed launch shape (staging array, scene derived data)
+        r.reset()
+        r.kernel_time()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            r.render_passes(seeds[(k + 1) * passes:(k + 2) * passes], first_buffer_spp=k * passes, sync=False)
+        r.sync()
+        dt = time.perf_counter() - t0
+        ms, launches = r.kernel_time()
+        info = r.kernel_info()
+        launch_ms = ms / max(launches, 1)
+        out = {"baseline_config": config, "workload": f"{what}, {sc.width}x{sc.height}, draw-depth 256, {passes} spp per step",
+               "value": round(n_pix * steps * passes / dt / 1e6, 3), "unit": "Msamples/s", "steps": steps, "passes_per_step": passes,
+               "ms_per_step": round(dt / steps * 1e3, 4), "launch_ms": round(launch_ms, 4), "launches": launches}
+        gold = golden_rows(golden_name)
+        if gold is not None:
+            r.reset()
+            r.render_passes(gold[0])
+            out["image_check"] = compare_golden(r.read(), gold, sc.width)
+        if not args.no_roofline:
+            out["roofline"], _, _ = roofline_object(sc, config, info, launch_ms, launches, n_pix * steps * passes // max(launches, 1),
+                                                    steps * passes // max(launches, 1), seeds, threads, 12, args.kernel, build_oracle=not args.no_cpu)
+        out["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
+        return out
+    finally:
+        r.close()
+        loader.close()
+
+
 def group_leg(devices, sc, seeds, passes, gold, kernel_variant):
     """One process, len(devices) GPUs behind one context (chunky_group_create): one step + the gather, timed on their own."""
     from chunkyclplugin_amd import native
@@ -223,7 +327,26 @@ def group_leg(devices, sc, seeds, passes, gold, kernel_variant):
         r.gather()
         t2 = time.perf_counter()
         ms, launches = r.kernel_time()
+        # the same gather once more through every transport the group can use (the first one above is the default's, warm)
+        transports = {}
+        default_t = inst.transport()
+        for t_id in (native.TRANSPORT_RCCL_SENDRECV, native.TRANSPORT_RCCL_REDUCE, native.TRANSPORT_PEER_COPY):
+            try:
+                inst.set_transport(t_id)
+            except native.ChunkyHipError as e:
+                transports[RendererInstance.TRANSPORT_NAMES[t_id]] = {"unavailable": str(e)[:200]}
+                continue
+            r.gather()  # (communicator channels / buffers of this transport come up here)
+            ta = time.perf_counter()
+            for _ in range(3):
+                r.gather()
+            transports[RendererInstance.TRANSPORT_NAMES[t_id]] = {"gather_ms": round((time.perf_counter() - ta) / 3 * 1e3, 3)}
+        try:
+            inst.set_transport(default_t["transport"])
+        except native.ChunkyHipError:
+            pass
         out = {"members": len(devices), "devices": [int(d) for d in devices], "peer_status": inst.peer_status(),
+               "transport": default_t, "transports_timed": transports, "transport_after": inst.transport(),
                "peer_status_legend": "0 local (member 0's device), 1 direct (peer access enabled: xGMI), 2 staged (no peer access), < 0 = -hipError",
                "passes": passes, "render_ms": round((t1 - t0) * 1e3, 3), "gather_ms": round((t2 - t1) * 1e3, 3),
                "kernel_ms_slowest_member": round(ms, 3),
@@ -256,6 +379,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the oracle row-sample too: nothing under oracle/ is loaded, built or spawned (profiler runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the end_to_end / image_check / group_check legs (profiler runs)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of BASELINE configs[1], [3], [4] in the default line")
     ap.add_argument("--group", type=int, default=0, help="N > 0: ONE process, N GPUs behind one context (chunky_group_create); "
                                                          "members share GPU 0 when the box has fewer than N")
     ap.add_argument("--dump", default="", help="rank 0 writes the final (reduced) framebuffer to this .npy file")
@@ -321,6 +445,8 @@ def main():
     fb = torch.zeros(3 * n_pix, dtype=torch.float32, device="cuda")
     # the read-back lands in a buffer of its own: rank 0's framebuffer must keep holding only rank 0's tiles
     image = torch.zeros_like(fb) if world > 1 else fb
+    # ... and from there in pinned host memory on rank 0 (the reference's passBuffer, OpenClPathTracingRenderer.java:164-166)
+    host_image = torch.empty(3 * n_pix, dtype=torch.float32, pin_memory=True) if rank == 0 else None
     torch.cuda.synchronize()  # the fill runs on torch's stream, the passes on the library's: order them (chunky_hip.h)
     r.set_device_buffer(fb.data_ptr())
 
@@ -334,12 +460,13 @@ def main():
             dist.barrier(group=ctl)
             torch.cuda.synchronize()
 
-    reduce_ms = []
+    reduce_ms, d2h_ms = [], []
 
     def read_back():
-        """What the reference does every merge interval (:162-178), as far as the device side goes: N > 1 — the one RCCL reduce
-        of the per-rank framebuffers onto rank 0 (into `image`); a group — the gather onto member 0; N = 1 — nothing, the
-        image is where the boundary leaves it (HBM)."""
+        """What the reference does every merge interval (:162-178) up to the merge: the exchange that assembles the image on
+        rank 0 / member 0 — N > 1: the one RCCL reduce of the per-rank framebuffers (into `image`); a group: the library's
+        one exchange (chunky_render_gather); N = 1: none — and then, at EVERY N, rank 0's copy of the image into pinned host
+        memory (clEnqueueReadBuffer, :164-166).  Both are inside the timed region."""
         r.sync()
         t = time.perf_counter()
         if world > 1:
@@ -348,16 +475,33 @@ def main():
             torch.cuda.synchronize()
         elif group_devices:
             r.gather()
-        reduce_ms.append((time.perf_counter() - t) * 1e3)
+        t1 = time.perf_counter()
+        if rank == 0:
+            if group_devices:
+                r.read(out=host_image.numpy())  # (gathered above: the second exchange inside is a few tens of microseconds)
+            else:
+                host_image.copy_(image)
+                torch.cuda.synchronize()
+        reduce_ms.append((t1 - t) * 1e3)
+        d2h_ms.append((time.perf_counter() - t1) * 1e3)
 
     if world > 1:  # the read-back collective once, untimed, on a scratch buffer: communicator and channel set-up are not the path
         if on_gpu:
-            ok = 1
-            try:
-                parallel.reduce_framebuffer(torch.zeros_like(fb), dst=0)
-                torch.cuda.synchronize()
-            except Exception as e:  # e.g. two ranks on one device, IPC refused: say so in the line and stage through the host
-                ok, rccl_error = 0, f"{type(e).__name__}: {str(e)[:300]}"
+            # the ranks first agree over gloo (host side) on who sits where: two ranks on one device can never share an RCCL
+            # communicator, and if only ONE of them failed inside the first collective the others would wait in it for ever —
+            # so that case never reaches RCCL at all
+            mine = [None] * world
+            dist.all_gather_object(mine, (local_rank, os.uname().nodename), group=ctl)
+            collide = len(set(mine)) < world
+            ok = 0 if collide else 1
+            if collide:
+                rccl_error = f"ranks share a device ({sorted(mine)}): no RCCL communicator is possible"
+            else:
+                try:
+                    parallel.reduce_framebuffer(torch.zeros_like(fb), dst=0)
+                    torch.cuda.synchronize()
+                except Exception as e:  # e.g. IPC refused: say so in the line and stage through the host
+                    ok, rccl_error = 0, f"{type(e).__name__}: {str(e)[:300]}"
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)   # every rank takes the same path
             if int(flag.item()) == 0:
@@ -398,10 +542,12 @@ def main():
     barrier()
     r.kernel_time()  # discard warmup launches
     reduce_ms.clear()
+    d2h_ms.clear()
     t0 = time.perf_counter()
     readbacks = run_steps(args.steps, args.warmup * passes)
     barrier()
     dt = time.perf_counter() - t0
+    my_d2h_ms = list(d2h_ms)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
@@ -513,21 +659,16 @@ def main():
         share = n_pix if group_devices else min(local_slots, n_pix)  # (a group reports its slowest member's kernels for the whole image)
         samples_per_launch = share * args.steps * passes // max(launches, 1)
         passes_per_launch = args.steps * passes // max(launches, 1)
-        bytes_per_sample, n_s, rows, cal = None, 0, [], None
+        roof, cal, rows = None, None, []
         if not args.no_roofline:
-            from oracle import binding
-            binding.port(build=not args.no_cpu)  # --no-cpu runs (profiler passes) never spawn a compiler
-            rows = sample_rows(sc.height, 36)
-            n_s, cal_dt, ctr = oracle_row_sample(sc, seeds[:1], rows, threads, count=True, pin=True)
-            bytes_per_sample = binding.algorithmic_bytes(ctr)
-            cal = n_s / max(cal_dt, 1e-6)
-        achieved = bytes_per_sample * samples_per_launch / (launch_ms * 1e-3) / 1e9 if (launch_ms > 0 and bytes_per_sample) else 0.0
-        bvh_tag = ",bvh" if info["bvh"] else ""
-        kernel_name = ("render_pool<%d,%d%s>+fold_kernel" % (info["tree"], info["pool"], bvh_tag) if info["pool"] >= 0 else
-                       "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh"))
-        pm = pmc_entry(args.config, info, passes_per_launch, samples_per_launch, args.kernel) if not group_devices else None
-        traffic = pm.get("hbm_bytes_per_launch") if pm else None
-        how = (f"{len(group_devices)} GPU(s) behind one context in one process (chunky_group_create), 16x16-pixel blocks round-robin, one gather per read-back"
+            roof, cal, rows = roofline_object(sc, args.config, info, launch_ms, launches, samples_per_launch, passes_per_launch, seeds, threads, 36,
+                                              args.kernel, attach_pmc=not group_devices, build_oracle=not args.no_cpu)
+        else:
+            roof = {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None,
+                    "kernel": kernel_label(info), "launches": launches, "launch_ms": round(launch_ms, 4), "samples_per_launch": samples_per_launch}
+        group_transport = inst.transport() if group_devices else None
+        how = (f"{len(group_devices)} GPU(s) behind one context in one process (chunky_group_create), 16x16-pixel blocks round-robin, "
+               f"one exchange per read-back inside the library ({group_transport['name']})"
                if group_devices else
                f"image tiles ({'16x16-pixel blocks' if args.tile == 0 else f'runs of {args.tile} px'}) round-robin over {world} GPU(s), scene replicated, "
                f"one RCCL reduce per read-back")
@@ -544,26 +685,28 @@ def main():
                        "octree_ints": int(sc.octree.size), "octree_depth": int(sc.octree_depth),
                        "entity_bvh_ints": int(len(sc.world_bvh) + len(sc.actor_bvh)),
                        "parallelism": how, "kernel_variant": args.kernel},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "achieved_is": "algorithmic bytes of the reference access stream / launch time (SURVEY 8d), "
-                                        "not physical HBM traffic: the scene is cache-resident",
-                         "physical_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and launch_ms > 0 else None,
-                         "valu": pm.get("valu") if pm else None, "limits": pm.get("limits") if pm else None,
-                         "pmc_source": pm.get("source") if pm else None,
-                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 1) if bytes_per_sample else None,
-                         "kernel": kernel_name, "launches": launches, "launch_ms": round(launch_ms, 4),
-                         "samples_per_launch": samples_per_launch,
-                         "counted_on": f"{n_s} samples ({len(rows)} rows of this view, seed 0)"},
+            "roofline": roof,
         }
+        # the same samples without the read-backs (exchange + copy to the host): what the kernels alone sustain with everything in HBM
+        rb_s = (sum(my_reduce_ms) + sum(my_d2h_ms)) * 1e-3
+        out["value_hbm_resident"] = round(samples / max(dt - rb_s, 1e-9) / 1e6, 3)
+        out["readback"] = {"count": readbacks, "exchange_ms": [round(x, 3) for x in my_reduce_ms], "to_host_ms": [round(x, 3) for x in my_d2h_ms],
+                           "bytes_to_host": 12 * n_pix, "in_value": True,
+                           "note": "every merge interval and at the end, at every N: the exchange that assembles the image on rank 0 (none at N = 1), "
+                                   "then rank 0's copy into pinned host memory — the reference's clEnqueueReadBuffer (OpenClPathTracingRenderer.java:164-166)"}
         if args.emulate_world:
             out["emulated_world"] = args.emulate_world
             out["metric"] += f" — EMULATED rank-0 share of a {args.emulate_world}-GPU split on one GPU (not a multi-GPU result)"
         # what the collective actually ran on: the backend and world size torch.distributed reports ("nccl" IS RCCL on ROCm);
         # a single process runs no communicator at all
         backend_used = None if world == 1 else ("nccl" if on_gpu else "gloo")
-        out["rccl_ranks"] = dist.get_world_size() if backend_used == "nccl" else 0
-        out["collective"] = {"backend": backend_used, "ranks": dist.get_world_size() if world > 1 else 1,
+        if group_devices:  # one process: the exchange runs inside libchunky_hip — RCCL bound from C++, or its peer-copy fallback
+            backend_used = group_transport["backend"]
+        out["rccl_ranks"] = (dist.get_world_size() if backend_used == "nccl" else
+                             (len(group_devices) if group_devices and backend_used == "rccl" else 0))
+        out["collective"] = {"backend": backend_used, "called_from": "libchunky_hip (C++, chunky_render_gather)" if group_devices else
+                                                                      ("torch.distributed" if world > 1 else None),
+                             "ranks": dist.get_world_size() if world > 1 else (len(group_devices) if group_devices else 1),
                              "devices": sorted(set(devices_seen)) if not group_devices else group_devices,
                              "readback_ms": [round(x, 3) for x in my_reduce_ms],
                              "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
@@ -572,7 +715,8 @@ def main():
             out["collective"]["rccl_failed"] = rccl_error or "on another rank"
             out["collective"]["note"] = "the first RCCL collective raised: read-backs were staged through the host and reduced over gloo"
         if group_devices:
-            out["group"] = {"members": len(group_devices), "devices": group_devices, "peer_status": inst.peer_status(),
+            out["collective"]["transport"] = group_transport
+            out["group"] = {"members": len(group_devices), "devices": group_devices, "peer_status": inst.peer_status(), "transport": group_transport,
                             "peer_status_legend": "0 local (member 0's device), 1 direct (peer access enabled: xGMI), 2 staged (no peer access), < 0 = -hipError",
                             "gather_ms": [round(x, 3) for x in my_reduce_ms]}
         if per_rank:
@@ -614,6 +758,17 @@ def main():
                 out["end_to_end"] = end_to_end_leg(loader, sc, e2e_spp, make_renderer)
             except Exception as e:
                 out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not group_devices and args.config == 2 and not args.no_extras and not args.emulate_world and not args.no_other_configs:
+            # the other BASELINE configurations, short and warm, in the same run on the same box (the headline's target is gone:
+            # its 6.4 GB staging array is not needed beside the 4K one of configs[4])
+            r.close()
+            legs = []
+            for cfg in (1, 3, 4):
+                try:
+                    legs.append(other_config_leg(inst, cfg, args, threads))
+                except Exception as e:
+                    legs.append({"baseline_config": cfg, "error": f"{type(e).__name__}: {e}"})
+            out["other_configs"] = legs
         if world == 1 and not args.no_cpu and not args.no_roofline and cal:
             # bounded CPU leg on the SAME view: whole image x P passes when the budget allows, else evenly spread whole rows x 1
             # pass — grown from the rate just measured until a run costs about --cpu-seconds on the usable host CPUs

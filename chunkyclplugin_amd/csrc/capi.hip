@@ -18,6 +18,7 @@
 
 #include "../../include/chunky_hip.h"
 #include "kernels.hpp"
+#include "rccl_dyn.hpp"
 #include "rt_device.hpp"
 #include "widetree.hpp"
 
@@ -62,6 +63,13 @@ struct chunky_ctx {
     // chunky_group_create: one member context per GPU; this object then only carries the lock and fans calls out
     std::vector<chunky_ctx*> members;
     std::vector<int> peer_status;  // per member: how its read-back copies reach member 0 (chunky_group_peer_status)
+    // the read-back exchange of a group (group_gather): one RCCL communicator per member when the collective library could be
+    // bound and the members are distinct devices, else empty — `transport` says what the next read-back will use and
+    // `transport_detail` why (chunky_group_transport)
+    std::vector<ncclComm_t> comms;
+    int transport = CHUNKY_TRANSPORT_PEER_COPY;
+    std::string transport_detail = "single device: no exchange";
+    bool self_exchange = false;  // test rigs (CHUNKY_GROUP_SELF_EXCHANGE=1): member 0's own blocks travel through the exchange too
 };
 
 struct DevBuf {
@@ -138,6 +146,13 @@ struct chunky_render {
     int launch_cap_most = 0;  // ... determined for launches of at most this many passes (kMaxPassesPerLaunch / kMaxPoolPasses)
     DevBuf seed_buf;      // seeds of a launch longer than the kernel-argument segment holds (render_pool)
     int reserve_passes = 0;  // the pass loop is about to climb to launches of this many passes: size the staging array once
+    struct SeedSlot {        // pinned host copies of long launches' seeds on their way to seed_buf
+        int32_t* host = nullptr;
+        hipEvent_t copied = nullptr;
+    };
+    static constexpr int kSeedSlots = 4;
+    SeedSlot seed_ring[kSeedSlots];
+    unsigned seed_next = 0;
     // on a group: one target per member (this object holds no device data), the caller's share of the image, and the buffers
     // of the read-back exchange: gather_send[i] on member i's device, gather_recv[i] on member 0's
     std::vector<chunky_render*> parts;
@@ -149,6 +164,10 @@ struct chunky_render {
             (void)hipEventDestroy(p.second);
         }
         for (auto e : free_events) (void)hipEventDestroy(e);
+        for (SeedSlot& s : seed_ring) {
+            if (s.copied) (void)hipEventDestroy(s.copied);
+            if (s.host) (void)hipHostFree(s.host);
+        }
     }
 };
 
@@ -217,6 +236,67 @@ extern "C" int chunky_init(int device, chunky_ctx** out) {
     return CHUNKY_OK;
 }
 
+// "rccl 2.22.3 (librccl.so.1), 8 ranks, grouped send/recv of the owned blocks"
+static std::string rccl_detail(const chunky_ctx* g, int transport) {
+    const RcclApi& api = rccl_api();
+    char buf[256];
+    snprintf(buf, sizeof buf, "rccl %d.%d.%d (%s), %zu rank(s), %s", api.version / 10000, (api.version / 100) % 100, api.version % 100,
+             api.where.c_str(), g->comms.size(),
+             transport == CHUNKY_TRANSPORT_RCCL_REDUCE ? "ncclReduce(sum) of the zero-padded framebuffers onto member 0"
+             : transport == CHUNKY_TRANSPORT_RCCL_SENDRECV ? "grouped ncclSend / ncclRecv of the owned blocks to member 0"
+                                                            : "communicator open, peer copies selected");
+    return buf;
+}
+
+// Gives up the communicators (after an RCCL failure, or at shutdown): later read-backs use peer copies.
+static void group_close_rccl(chunky_ctx* g, bool abort) {
+    const RcclApi& api = rccl_api();
+    for (size_t i = 0; i < g->comms.size(); i++) {
+        (void)hipSetDevice(g->members[i]->device);
+        if (g->comms[i]) (void)(abort ? api.CommAbort(g->comms[i]) : api.CommDestroy(g->comms[i]));
+    }
+    g->comms.clear();
+    (void)hipGetLastError();
+}
+
+// One RCCL communicator over the members of a group (chunky_group_transport).  Never an error: without it the exchange
+// runs on peer copies and transport_detail says why.
+static void group_open_rccl(chunky_ctx* g, const int* devices, int n) {
+    g->transport = CHUNKY_TRANSPORT_PEER_COPY;
+    const char* env = getenv("CHUNKY_GROUP_TRANSPORT");
+    const std::string want = env ? env : "";
+    const char* self = getenv("CHUNKY_GROUP_SELF_EXCHANGE");
+    g->self_exchange = self && *self && *self != '0';
+    if (want == "peer") {
+        g->transport_detail = "peer copies: CHUNKY_GROUP_TRANSPORT=peer";
+        return;
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (devices[i] == devices[j] && !(getenv("CHUNKY_RCCL_TRY_SHARED"))) {
+                // (ncclCommInitAll refuses a device list with duplicates; CHUNKY_RCCL_TRY_SHARED lets the tests watch it do so)
+                char buf[128];
+                snprintf(buf, sizeof buf, "peer copies: members %d and %d share device %d (one RCCL rank per device)", j, i, devices[i]);
+                g->transport_detail = buf;
+                return;
+            }
+    const RcclApi& api = rccl_api();
+    if (!api.usable()) {
+        g->transport_detail = "peer copies: " + api.error;
+        return;
+    }
+    g->comms.assign((size_t)n, nullptr);
+    const ncclResult_t rc = api.CommInitAll(g->comms.data(), n, devices);
+    if (rc != ncclSuccess) {
+        g->comms.clear();
+        (void)hipGetLastError();
+        g->transport_detail = std::string("peer copies: ncclCommInitAll: ") + api.str(rc);
+        return;
+    }
+    g->transport = want == "rccl-reduce" ? CHUNKY_TRANSPORT_RCCL_REDUCE : CHUNKY_TRANSPORT_RCCL_SENDRECV;
+    g->transport_detail = rccl_detail(g, g->transport);
+}
+
 extern "C" int chunky_group_create(const int* devices, int n, chunky_ctx** out) {
     if (!out) return fail(CHUNKY_E_INVALID, "chunky_group_create: out is NULL");
     *out = nullptr;
@@ -252,7 +332,30 @@ extern "C" int chunky_group_create(const int* devices, int n, chunky_ctx** out) 
         }
         (void)hipGetLastError();
     }
+    group_open_rccl(g.get(), devices, n);
+    (void)hipSetDevice(g->device);
     *out = g.release();
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_group_transport(chunky_ctx* ctx, int* transport, char* detail, int detail_len) {
+    if (!ctx || !transport) return fail(CHUNKY_E_INVALID, "chunky_group_transport: NULL argument");
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
+    *transport = ctx->transport;
+    if (detail && detail_len > 0) snprintf(detail, (size_t)detail_len, "%s", ctx->transport_detail.c_str());
+    return CHUNKY_OK;
+}
+
+extern "C" int chunky_group_set_transport(chunky_ctx* ctx, int transport) {
+    if (!ctx) return fail(CHUNKY_E_INVALID, "chunky_group_set_transport: NULL context");
+    if (transport != CHUNKY_TRANSPORT_PEER_COPY && transport != CHUNKY_TRANSPORT_RCCL_SENDRECV && transport != CHUNKY_TRANSPORT_RCCL_REDUCE)
+        return fail(CHUNKY_E_INVALID, "chunky_group_set_transport: unknown transport %d", transport);
+    std::lock_guard<std::recursive_mutex> g(ctx->mu);
+    if (transport == ctx->transport) return CHUNKY_OK;
+    if (transport != CHUNKY_TRANSPORT_PEER_COPY && ctx->comms.empty())
+        return fail(CHUNKY_E_STATE, "chunky_group_set_transport: no RCCL communicator (%s)", ctx->transport_detail.c_str());
+    ctx->transport = transport;
+    if (!ctx->comms.empty()) ctx->transport_detail = rccl_detail(ctx, transport);
     return CHUNKY_OK;
 }
 
@@ -280,6 +383,13 @@ extern "C" int chunky_shutdown(chunky_ctx* ctx) {
     if (!ctx) return fail(CHUNKY_E_INVALID, "chunky_shutdown: NULL context");
     if (!ctx->members.empty()) {
         int rc = CHUNKY_OK;
+        if (!ctx->comms.empty()) {  // (the members' streams are idle by the contract of shutdown: no render target is left)
+            for (chunky_ctx* m : ctx->members) {
+                (void)hipSetDevice(m->device);
+                (void)hipStreamSynchronize(m->stream);
+            }
+            group_close_rccl(ctx, false);
+        }
         for (chunky_ctx* m : ctx->members)
             if (int e = chunky_shutdown(m)) rc = e;
         delete ctx;
@@ -1394,8 +1504,11 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
             int ahead = r->reserve_passes < r->launch_cap ? r->reserve_passes : r->launch_cap;
             if (ahead > kMaxPassesPerLaunch) ahead = kMaxPassesPerLaunch;  // (the pass loop's own launches stop there)
             if (ahead > ps.n) {
-                const size_t want = staging_floats(r->shard, r->width, r->height, ahead) * sizeof(float);
-                if (hipMalloc(&r->staging.p, want) == hipSuccess) {
+                size_t want = staging_floats(r->shard, r->width, r->height, ahead) * sizeof(float);
+                size_t free_b = 0, total_b = 0;  // never more than half of what the device has left: other targets and members live there too
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = 0;
+                (void)hipGetLastError();
+                if (want >= need && hipMalloc(&r->staging.p, want) == hipSuccess) {
                     r->staging.bytes = want;
                 } else {
                     (void)hipGetLastError();
@@ -1424,7 +1537,18 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
                 HIP_TRY(hipMalloc(&r->seed_buf.p, (size_t)kMaxPoolPasses * 4));
                 r->seed_buf.bytes = (size_t)kMaxPoolPasses * 4;
             }
-            HIP_TRY(hipMemcpyAsync(r->seed_buf.p, seeds + done, (size_t)ps.n * 4, hipMemcpyHostToDevice, r->ctx->stream));
+            // from a pinned slot of the target's own (the caller may reuse or free `seeds` as soon as this call returns — the JNI
+            // glue releases the Java array — and a copy out of pageable memory is only safe if the runtime happens to stage it)
+            chunky_render::SeedSlot& slot = r->seed_ring[r->seed_next++ % chunky_render::kSeedSlots];
+            if (!slot.host) {
+                HIP_TRY(hipHostMalloc((void**)&slot.host, (size_t)kMaxPoolPasses * 4, hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&slot.copied, hipEventDisableTiming));
+            } else {
+                HIP_TRY(hipEventSynchronize(slot.copied));  // the copy that read this slot last (kSeedSlots launches ago)
+            }
+            memcpy(slot.host, seeds + done, (size_t)ps.n * 4);
+            HIP_TRY(hipMemcpyAsync(r->seed_buf.p, slot.host, (size_t)ps.n * 4, hipMemcpyHostToDevice, r->ctx->stream));
+            HIP_TRY(hipEventRecord(slot.copied, r->ctx->stream));
             seeds_dev = (const int*)r->seed_buf.p;
         }
         hipEvent_t e0, e1;
@@ -1448,30 +1572,48 @@ extern "C" int chunky_render_sync(chunky_render* r) {
 }
 
 // The one exchange per read-back of a group: every member but the first packs the pixels of the
-// blocks it owns (3 floats each, in the order of its pixel slots), copies them into member 0's memory, and member 0
+// blocks it owns (3 floats each, in the order of its pixel slots), they travel into member 0's memory, and member 0
 // scatters them into the image.  Blocks are disjoint, so this is the "reduce of per-tile radiance" with 1/n of the bytes
-// per member and no arithmetic: the image is bit for bit what one GPU renders.
-static int group_gather(chunky_render* r) {
+// per member and no arithmetic: the image is bit for bit what one GPU renders.  What carries them is the group's
+// transport (chunky_group_transport): ONE grouped RCCL send / receive, or peer copies; CHUNKY_TRANSPORT_RCCL_REDUCE is
+// the literal form instead — one ncclReduce(sum) of the zero-padded framebuffers.
+static int gather_buffers(chunky_render* r, size_t i, size_t bytes) {
+    chunky_render* pi = r->parts[i];
+    if (r->gather_recv[i].bytes < bytes) {
+        HIP_TRY(hipSetDevice(r->parts[0]->ctx->device));
+        r->gather_recv[i].release();
+        HIP_TRY(hipMalloc(&r->gather_recv[i].p, bytes));
+        r->gather_recv[i].bytes = bytes;
+    }
+    HIP_TRY(hipSetDevice(pi->ctx->device));
+    if (r->gather_send[i].bytes < bytes) {
+        r->gather_send[i].release();
+        HIP_TRY(hipMalloc(&r->gather_send[i].p, bytes));
+        r->gather_send[i].bytes = bytes;
+    }
+    return CHUNKY_OK;
+}
+// member 0 scatters what arrived and the host waits for it
+static int gather_scatter(chunky_render* r, size_t first) {
     chunky_render* p0 = r->parts[0];
-    const int dev0 = p0->ctx->device;
+    std::lock_guard<std::recursive_mutex> g0(p0->ctx->mu);
+    HIP_TRY(hipSetDevice(p0->ctx->device));
+    for (size_t i = first; i < r->parts.size(); i++)
+        if (r->parts[i]->shard.n_local > 0)
+            HIP_TRY(launch_gather(false, r->parts[i]->shard, p0->width, p0->height, p0->fb, (float*)r->gather_recv[i].p, p0->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p0->ctx->stream));
+    return CHUNKY_OK;
+}
+
+static int group_gather_peer(chunky_render* r) {
+    const int dev0 = r->parts[0]->ctx->device;
     const size_t n = r->parts.size();
     for (size_t i = 1; i < n; i++) {
         chunky_render* pi = r->parts[i];
         std::lock_guard<std::recursive_mutex> gi(pi->ctx->mu);
         const size_t bytes = (size_t)pi->shard.n_local * 3 * sizeof(float);
         if (bytes == 0) continue;
-        if (r->gather_recv[i].bytes < bytes) {
-            HIP_TRY(hipSetDevice(dev0));
-            r->gather_recv[i].release();
-            HIP_TRY(hipMalloc(&r->gather_recv[i].p, bytes));
-            r->gather_recv[i].bytes = bytes;
-        }
-        HIP_TRY(hipSetDevice(pi->ctx->device));
-        if (r->gather_send[i].bytes < bytes) {
-            r->gather_send[i].release();
-            HIP_TRY(hipMalloc(&r->gather_send[i].p, bytes));
-            r->gather_send[i].bytes = bytes;
-        }
+        if (int rc = gather_buffers(r, i, bytes)) return rc;
         // on member i's stream, behind its queued passes: pack, then the copy across
         HIP_TRY(launch_gather(true, pi->shard, pi->width, pi->height, pi->fb, (float*)r->gather_send[i].p, pi->ctx->stream));
         if (pi->ctx->device == dev0)
@@ -1483,13 +1625,116 @@ static int group_gather(chunky_render* r) {
         HIP_TRY(hipSetDevice(r->parts[i]->ctx->device));
         HIP_TRY(hipStreamSynchronize(r->parts[i]->ctx->stream));
     }
-    std::lock_guard<std::recursive_mutex> g0(p0->ctx->mu);
-    HIP_TRY(hipSetDevice(dev0));
-    for (size_t i = 1; i < n; i++)
-        if (r->parts[i]->shard.n_local > 0)
-            HIP_TRY(launch_gather(false, r->parts[i]->shard, p0->width, p0->height, p0->fb, (float*)r->gather_recv[i].p, p0->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(p0->ctx->stream));
+    return gather_scatter(r, 1);
+}
+
+#define RCCL_TRY(expr)                                                                           \
+    do {                                                                                         \
+        const ncclResult_t e_ = (expr);                                                          \
+        if (e_ != ncclSuccess) {                                                                 \
+            if (in_group) (void)api.GroupEnd();                                                  \
+            return fail(CHUNKY_E_HIP, "%s: %s", #expr, api.str(e_));                             \
+        }                                                                                        \
+    } while (0)
+
+// ONE grouped RCCL operation: member i's ncclSend of its packed blocks on its own stream (behind its queued passes and the
+// pack kernel), member 0's matching ncclRecv's on its stream (ahead of the scatter kernels).
+static int group_gather_sendrecv(chunky_render* r) {
+    const RcclApi& api = rccl_api();
+    chunky_ctx* g = r->ctx;
+    chunky_render* p0 = r->parts[0];
+    const size_t n = r->parts.size(), first = g->self_exchange ? 0 : 1;
+    bool in_group = false;
+    for (size_t i = first; i < n; i++) {
+        chunky_render* pi = r->parts[i];
+        std::lock_guard<std::recursive_mutex> gi(pi->ctx->mu);
+        const size_t bytes = (size_t)pi->shard.n_local * 3 * sizeof(float);
+        if (bytes == 0) continue;
+        if (int rc = gather_buffers(r, i, bytes)) return rc;
+        HIP_TRY(launch_gather(true, pi->shard, pi->width, pi->height, pi->fb, (float*)r->gather_send[i].p, pi->ctx->stream));
+    }
+    RCCL_TRY(api.GroupStart());
+    in_group = true;
+    for (size_t i = first; i < n; i++) {
+        chunky_render* pi = r->parts[i];
+        const size_t count = (size_t)pi->shard.n_local * 3;
+        if (count == 0) continue;
+        HIP_TRY(hipSetDevice(pi->ctx->device));
+        RCCL_TRY(api.Send(r->gather_send[i].p, count, ncclFloat, 0, g->comms[i], pi->ctx->stream));
+        HIP_TRY(hipSetDevice(p0->ctx->device));
+        RCCL_TRY(api.Recv(r->gather_recv[i].p, count, ncclFloat, (int)i, g->comms[0], p0->ctx->stream));
+    }
+    in_group = false;
+    RCCL_TRY(api.GroupEnd());
+    if (int rc = gather_scatter(r, first)) return rc;  // (waits for member 0's stream: the receives are complete)
+    for (size_t i = 1; i < n; i++) {
+        HIP_TRY(hipSetDevice(r->parts[i]->ctx->device));
+        HIP_TRY(hipStreamSynchronize(r->parts[i]->ctx->stream));
+    }
+    for (size_t i = 0; i < n; i++) {  // a failure the communicator noticed by itself (a dead link, a dead peer)
+        ncclResult_t async = ncclSuccess;
+        if (api.CommGetAsyncError(g->comms[i], &async) == ncclSuccess && async != ncclSuccess)
+            return fail(CHUNKY_E_HIP, "RCCL communicator of member %zu: %s", i, api.str(async));
+    }
     return CHUNKY_OK;
+}
+
+// The literal form: member 0 clears what it does not own (the blocks earlier read-backs left there), every member's
+// framebuffer is then zero outside its own blocks, and ONE ncclReduce(sum) onto member 0 assembles the image in place.
+static int group_gather_reduce(chunky_render* r) {
+    const RcclApi& api = rccl_api();
+    chunky_ctx* g = r->ctx;
+    chunky_render* p0 = r->parts[0];
+    const size_t n = r->parts.size();
+    const size_t count = (size_t)p0->width * p0->height * 3;
+    bool in_group = false;
+    {
+        std::lock_guard<std::recursive_mutex> g0(p0->ctx->mu);
+        HIP_TRY(hipSetDevice(p0->ctx->device));
+        HIP_TRY(launch_clear_foreign(p0->shard, p0->width, p0->height, p0->fb, p0->ctx->stream));
+    }
+    RCCL_TRY(api.GroupStart());
+    in_group = true;
+    for (size_t i = 0; i < n; i++) {
+        chunky_render* pi = r->parts[i];
+        HIP_TRY(hipSetDevice(pi->ctx->device));
+        RCCL_TRY(api.Reduce(pi->fb, pi->fb, count, ncclFloat, ncclSum, 0, g->comms[i], pi->ctx->stream));
+    }
+    in_group = false;
+    RCCL_TRY(api.GroupEnd());
+    for (size_t i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(r->parts[i]->ctx->device));
+        HIP_TRY(hipStreamSynchronize(r->parts[i]->ctx->stream));
+    }
+    for (size_t i = 0; i < n; i++) {
+        ncclResult_t async = ncclSuccess;
+        if (api.CommGetAsyncError(g->comms[i], &async) == ncclSuccess && async != ncclSuccess)
+            return fail(CHUNKY_E_HIP, "RCCL communicator of member %zu: %s", i, api.str(async));
+    }
+    HIP_TRY(hipSetDevice(p0->ctx->device));
+    return CHUNKY_OK;
+}
+#undef RCCL_TRY
+
+static int group_gather(chunky_render* r) {
+    chunky_ctx* g = r->ctx;
+    if (g->transport != CHUNKY_TRANSPORT_PEER_COPY && !g->comms.empty()) {
+        const int rc = g->transport == CHUNKY_TRANSPORT_RCCL_REDUCE ? group_gather_reduce(r) : group_gather_sendrecv(r);
+        if (rc == CHUNKY_OK) return rc;
+        // An RCCL call failed: the render must not be lost with it.  The members' own blocks are intact (the exchange only
+        // ever writes buffers of its own, and — the reduce — pixels of member 0's image that member 0 does not own), so the
+        // same read-back runs again on peer copies, and so does every later one; chunky_group_transport says why.
+        const std::string why = tls_error;
+        for (chunky_render* part : r->parts) {
+            (void)hipSetDevice(part->ctx->device);
+            (void)hipStreamSynchronize(part->ctx->stream);
+        }
+        (void)hipGetLastError();
+        group_close_rccl(g, true);
+        g->transport = CHUNKY_TRANSPORT_PEER_COPY;
+        g->transport_detail = "peer copies: " + why;
+    }
+    return group_gather_peer(r);
 }
 
 extern "C" int chunky_render_gather(chunky_render* r) {
@@ -1550,7 +1795,14 @@ extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]) {
     out8[3] = r->last_choice.blocks;
     out8[4] = r->last_choice.pool;
     out8[5] = r->last_choice.ext;
-    out8[6] = r->launch_cap > 0 ? r->launch_cap : launch_pass_cap(r, kStagingBytes);  // (of the kernel family that ran last)
+    if (r->launch_cap > 0) {
+        out8[6] = r->launch_cap;  // (of the kernel family that ran last)
+    } else {  // before the first launch: what chunky_render_passes is going to decide for this scene and option set
+        SceneView S;
+        int most = kMaxPassesPerLaunch;
+        if (scene_view(r->scene, &S, false) == CHUNKY_OK && pool_kernel_applies(r->kernel_variant, S, r->opts, r->work_counter.p != nullptr)) most = kMaxPoolPasses;
+        out8[6] = launch_pass_cap(r, kStagingBytes, most);
+    }
     return CHUNKY_OK;
 }
 
@@ -1649,12 +1901,18 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
     int samp_spp = *scene_spp;         // sceneSpp[0], :92
     auto last_callback = std::chrono::steady_clock::now();
     if (int rc = chunky_render_reset(r)) return rc;  // new float[] passBuffer uploaded with the buffer, :61,71
-    {   // the launches below grow to what fits 95 ms: let the first one size the staging array for that
-        const int ahead = target_spp - *scene_spp < merge_interval ? target_spp - *scene_spp : merge_interval;
-        std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
-        if (r->parts.empty()) r->reserve_passes = ahead;
-        for (chunky_render* part : r->parts) part->reserve_passes = ahead;
-    }
+    // The launches below grow to what fits 95 ms.  Once the climb has shown where it is heading (a launch of 8 passes or more is
+    // next), the staging array is sized ONCE for the launch size it will settle at instead of being regrown at every step; a
+    // heavy scene that settles at a few passes never reserves anything.  The hint is dropped when the loop ends, however it ends.
+    struct Reserve {
+        chunky_render* r;
+        void set(int passes) {
+            std::lock_guard<std::recursive_mutex> g(r->ctx->mu);
+            if (r->parts.empty()) r->reserve_passes = passes;
+            for (chunky_render* part : r->parts) part->reserve_passes = passes;
+        }
+        ~Reserve() { set(0); }
+    } reserve{r};
     int launch_passes = 1;             // adapts to ~95 ms per launch (below), so postRender is polled often enough
     while (logical_spp < target_spp) { // :102
         int buffer_spp = 0;            // bufferSppReal
@@ -1691,6 +1949,8 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
                 if (want > kMaxPassesPerLaunch) want = kMaxPassesPerLaunch;
                 if (want < 1) want = 1;
                 if (want > launch_passes || ms > 90.0) launch_passes = want;
+                // where the climb is heading: the rate just measured says how many passes fit 95 ms
+                if (launch_passes >= 8) reserve.set(per_pass > 0.0 && 95.0 / per_pass < (double)merge_interval ? (int)(95.0 / per_pass) + 1 : merge_interval);
             }
             if (!save && cb.post_render && std::chrono::duration<double, std::milli>(t1 - last_callback).count() > 100.0 &&
                 (!cb.poll_gate || cb.poll_gate(cb.user))) {  // :153-157; the gate is `!manager.shouldFinalize()` (:154)

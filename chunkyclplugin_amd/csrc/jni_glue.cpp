@@ -141,6 +141,23 @@ JNIEXPORT void JNICALL J(groupPeerStatus)(JNIEnv* env, jclass, jlong ctx, jintAr
     env->ReleaseIntArrayElements(out, p, rc == CHUNKY_OK ? 0 : JNI_ABORT);
     CHECK(rc);
 }
+JNIEXPORT jint JNICALL J(groupTransport)(JNIEnv* env, jclass, jlong ctx) {
+    int t = 0;
+    if (chunky_group_transport((chunky_ctx*)ctx, &t, nullptr, 0) != CHUNKY_OK) throw_last(env);
+    return t;
+}
+JNIEXPORT jstring JNICALL J(groupTransportDetail)(JNIEnv* env, jclass, jlong ctx) {
+    int t = 0;
+    char detail[512];
+    if (chunky_group_transport((chunky_ctx*)ctx, &t, detail, sizeof detail) != CHUNKY_OK) {
+        throw_last(env);
+        return nullptr;
+    }
+    return env->NewStringUTF(detail);
+}
+JNIEXPORT void JNICALL J(groupSetTransport)(JNIEnv* env, jclass, jlong ctx, jint transport) {
+    CHECK(chunky_group_set_transport((chunky_ctx*)ctx, transport));
+}
 JNIEXPORT void JNICALL J(shutdown)(JNIEnv* env, jclass, jlong ctx) { CHECK(chunky_shutdown((chunky_ctx*)ctx)); }
 JNIEXPORT jlong JNICALL J(sceneCreate)(JNIEnv* env, jclass, jlong ctx) {
     chunky_scene* s = nullptr;

@@ -99,6 +99,8 @@ hipError_t launch_fallback(int variant, const SceneView& S, const CameraView& C,
 // read-back exchange of a multi-GPU group: pack = true copies the pixels of this shard's slots from the image `fb` to `packed`
 // (3 floats per slot, padding slots skipped), pack = false scatters them back into an image
 hipError_t launch_gather(bool pack, const ShardView& T, int width, int height, float* fb, float* packed, hipStream_t stream);
+// ... and, for the exchange by ncclReduce, zeroes every pixel of `fb` that shard T does not own
+hipError_t launch_clear_foreign(const ShardView& T, int width, int height, float* fb, hipStream_t stream);
 hipError_t launch_trace_records(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, int seed,
                                 const int* gids_dev, int n, HitRecord* out, int* counts, float* radiance,
                                 hipStream_t stream);

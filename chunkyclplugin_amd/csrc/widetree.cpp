@@ -21,7 +21,9 @@ int default_wide_levels(int depth, int* level_bits) {
             while (*p && *p != ',') p++;
             if (*p == ',') p++;
         }
-        if (n >= 1 && sum == depth) {
+        bool sane = n >= 1 && sum == depth;
+        for (int i = 0; i < n; i++) sane = sane && b[i] >= 1 && b[i] <= 7;  // a level of 7 bits is 128^3 entries (8 MiB); anything else is ignored
+        if (sane) {
             for (int i = 0; i < n; i++) level_bits[i] = b[i];
             return n;
         }
@@ -29,7 +31,7 @@ int default_wide_levels(int depth, int* level_bits) {
     int most_top = 6;
     if (const char* e = getenv("CHUNKY_WIDE_TOP_BITS")) {  // tuning runs: a larger dense top (7: 128^3 entries = 8 MiB) for one level less
         const int v = atoi(e);
-        if (v >= 4 && v <= 8) most_top = v;
+        if (v >= 4 && v <= 7) most_top = v;
     }
     int n3 = depth <= most_top ? 0 : (depth - most_top + 2) / 3;
     if (n3 > kWideMaxLevels - 1) n3 = kWideMaxLevels - 1;

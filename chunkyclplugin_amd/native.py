@@ -29,6 +29,7 @@ PALETTE_BLOCK, PALETTE_MATERIAL, PALETTE_AABB, PALETTE_QUAD, PALETTE_TRIG = rang
 BVH_WORLD, BVH_ACTOR = 0, 1
 OPT_DRAW_DEPTH, OPT_MAX_DEPTH, OPT_EMITTER_SCALE, OPT_KERNEL, OPT_SUN_SAMPLING, OPT_EMITTERS, OPT_BSDF, OPT_EMITTER_NEE, OPT_BVH_CULL_BEHIND = range(9)
 PEER_LOCAL, PEER_DIRECT, PEER_STAGED = 0, 1, 2
+TRANSPORT_PEER_COPY, TRANSPORT_RCCL_SENDRECV, TRANSPORT_RCCL_REDUCE = 0, 1, 2
 E_INVALID, E_NO_DEVICE, E_HIP, E_STATE, E_ABORTED = -1, -2, -3, -4, -5
 
 
@@ -127,6 +128,8 @@ def lib() -> C.CDLL:
             "chunky_group_size": [vp],
             "chunky_group_device": [vp, C.c_int],
             "chunky_group_peer_status": [vp, vp, C.c_int],
+            "chunky_group_transport": [vp, C.POINTER(C.c_int), C.c_char_p, C.c_int],
+            "chunky_group_set_transport": [vp, C.c_int],
             "chunky_scene_create": [vp, C.POINTER(vp)],
             "chunky_scene_destroy": [vp],
             "chunky_scene_set_octree": [vp, vp, i64, C.c_int],

@@ -68,6 +68,23 @@ class RendererInstance:
         check(native.lib().chunky_group_peer_status(self._h, out, n))
         return list(out)
 
+    TRANSPORT_NAMES = {native.TRANSPORT_PEER_COPY: "peer-copy", native.TRANSPORT_RCCL_SENDRECV: "rccl-sendrecv",
+                       native.TRANSPORT_RCCL_REDUCE: "rccl-reduce"}
+
+    def transport(self) -> dict:
+        """chunky_group_transport: what carries the one exchange per read-back — {"transport": native.TRANSPORT_*, "name",
+        "backend": "rccl" | "peer-copy", "detail": library / version / ranks, or the reason for the peer-copy fallback}."""
+        t = C.c_int()
+        buf = C.create_string_buffer(512)
+        check(native.lib().chunky_group_transport(self._h, C.byref(t), buf, len(buf)))
+        return {"transport": t.value, "name": self.TRANSPORT_NAMES.get(t.value, str(t.value)),
+                "backend": "peer-copy" if t.value == native.TRANSPORT_PEER_COPY else "rccl",
+                "detail": buf.value.decode("utf-8", "replace")}
+
+    def set_transport(self, transport: int) -> None:
+        """chunky_group_set_transport (ChunkyHipError with code E_STATE when it needs an RCCL communicator that is not there)."""
+        check(native.lib().chunky_group_set_transport(self._h, int(transport)))
+
     @staticmethod
     def device_count() -> int:
         return native.lib().chunky_device_count()
@@ -224,8 +241,11 @@ class HipPathTracingRenderer:
         """The read-back exchange without the copy to the host (a group: member 0's device buffer then holds the image)."""
         check(native.lib().chunky_render_gather(self._h))
 
-    def read(self) -> np.ndarray:
-        out = np.empty(self.width * self.height * 3, np.float32)
+    def read(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """chunky_render_read (on a group: the one exchange, then the copy); `out` = a float32 array to fill — e.g. pinned memory."""
+        if out is None:
+            out = np.empty(self.width * self.height * 3, np.float32)
+        assert out.dtype == np.float32 and out.size == self.width * self.height * 3 and out.flags["C_CONTIGUOUS"]
         check(native.lib().chunky_render_read(self._h, ptr(out), out.size))
         return out
 

@@ -51,9 +51,9 @@ int chunky_shutdown(chunky_ctx* ctx);
  * uploads to all of them); a render target created on it is cut into blocks of 16 x 16 pixels dealt round-robin to the members
  * (member i renders blocks b with b % n == i, `gid` stays the global pixel index, so seeds and results are those of one GPU);
  * chunky_render_passes enqueues every member's share and returns; chunky_render_read is the one exchange per read-back: each
- * member packs the blocks it owns, copies them to member 0 (hipMemcpyPeerAsync: xGMI where peer access exists; 1/n of the
- * image per member, no collective library) where they are scattered into the image, which is then read back — bit for bit the
- * one-GPU image.  `devices` may name a device more than once (members then share it: how the path is tested on a 1-GPU box).
+ * member packs the blocks it owns and sends them to member 0 (one grouped RCCL send / receive over xGMI, or peer copies where
+ * RCCL is not available: chunky_group_transport; 1/n of the image per member) where they are scattered into the image, which is
+ * then read back — bit for bit the one-GPU image.  `devices` may name a device more than once (members then share it: how the path is tested on a 1-GPU box).
  * chunky_shutdown destroys the members. */
 int chunky_group_create(const int* devices, int n, chunky_ctx** out);
 /* Members of a context: 1 for chunky_init's, n for chunky_group_create's. */
@@ -69,6 +69,28 @@ int chunky_group_device(chunky_ctx* ctx, int i);
 #define CHUNKY_PEER_DIRECT 1
 #define CHUNKY_PEER_STAGED 2
 int chunky_group_peer_status(chunky_ctx* ctx, int* out, int n);
+/* What carries the one exchange per read-back of a group (no reference counterpart: one device, one queue,
+ * RendererInstance.java:74-101; SURVEY.md section 8e "a single RCCL reduce of per-tile radiance over xGMI").
+ * chunky_group_create binds RCCL at run time (dlopen: the collective library is not a link dependency; CHUNKY_RCCL_LIB names
+ * the file, else librccl.so.1) and opens one communicator over the members (ncclCommInitAll) when they are distinct devices:
+ *   CHUNKY_TRANSPORT_RCCL_SENDRECV  each member packs the blocks it owns and ncclSend's them, member 0 posts the matching
+ *                                   ncclRecv's — ONE grouped RCCL operation per read-back, 1/n of the image per member —
+ *                                   and scatters them into the image (the default when the communicator exists);
+ *   CHUNKY_TRANSPORT_RCCL_REDUCE    ONE ncclReduce(sum) of the members' zero-padded framebuffers onto member 0, as SURVEY
+ *                                   words it: every member moves the whole image, x + 0 = x keeps it bit-identical;
+ *   CHUNKY_TRANSPORT_PEER_COPY      the packed blocks travel by hipMemcpyPeerAsync (chunky_group_peer_status says how):
+ *                                   the fallback when RCCL cannot be bound, the communicator cannot be created (members
+ *                                   sharing a device), or an RCCL call fails later — the render survives and `detail` says why.
+ * All three leave the same bytes in member 0's image.  chunky_group_transport reports the transport the next read-back will
+ * use and a human-readable detail (library file and version, or the reason for the fallback); chunky_group_set_transport
+ * picks one (CHUNKY_E_STATE when it needs a communicator that does not exist).  The environment variable
+ * CHUNKY_GROUP_TRANSPORT = peer | rccl | rccl-reduce sets the initial choice.  On a chunky_init context: PEER_COPY, nothing
+ * to exchange. */
+#define CHUNKY_TRANSPORT_PEER_COPY 0
+#define CHUNKY_TRANSPORT_RCCL_SENDRECV 1
+#define CHUNKY_TRANSPORT_RCCL_REDUCE 2
+int chunky_group_transport(chunky_ctx* ctx, int* transport, char* detail, int detail_len);
+int chunky_group_set_transport(chunky_ctx* ctx, int transport);
 const char* chunky_last_error(void);
 /* Library identity: "chunky-hip <version> gfx950". */
 const char* chunky_version(void);

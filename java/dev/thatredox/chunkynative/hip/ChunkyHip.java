@@ -34,6 +34,8 @@ public class ChunkyHip implements Plugin {
                     if (peers[i] != HipNative.PEER_DIRECT && peers[i] != HipNative.PEER_LOCAL)
                         Log.warn("ChunkyHip: GPU " + devices[i] + " has no peer access to GPU " + devices[0] + " (status "
                                 + peers[i] + "): its share of every read-back is staged through the host.");
+                // one RCCL exchange over xGMI per read-back where the collective library could be bound, peer copies otherwise
+                Log.info("ChunkyHip: read-back exchange: " + HipNative.groupTransportDetail(ctx));
             }
         } catch (UnsatisfiedLinkError | RuntimeException e) {
             Log.error("Failed to load ChunkyHip. Could not load libchunky_hip or no gfx950 device.", e);

@@ -28,6 +28,14 @@ public final class HipNative {
      *  PEER_STAGED (no peer access between the two devices), or a negated HIP error when enabling peer access failed.
      *  out.length must be groupSize(ctx). */
     public static native void groupPeerStatus(long ctx, int[] out);
+    /** chunky_group_transport: what carries the one exchange per read-back of a group — TRANSPORT_RCCL_SENDRECV (one grouped
+     *  RCCL send / receive of the owned blocks; the default where RCCL could be bound), TRANSPORT_RCCL_REDUCE (one ncclReduce of
+     *  the zero-padded framebuffers) or TRANSPORT_PEER_COPY (the fallback) — and, as text, the library / version / ranks or the
+     *  reason for the fallback. */
+    public static native int groupTransport(long ctx);
+    public static native String groupTransportDetail(long ctx);
+    /** chunky_group_set_transport; RuntimeException when it needs an RCCL communicator that does not exist. */
+    public static native void groupSetTransport(long ctx, int transport);
     public static native void shutdown(long ctx);
 
     // scene — replaces ClIntBuffer / ClTextureLoader / ClSky uploads (ClSceneLoader.java:52-150)
@@ -86,6 +94,7 @@ public final class HipNative {
     public static final int PALETTE_BLOCK = 0, PALETTE_MATERIAL = 1, PALETTE_AABB = 2, PALETTE_QUAD = 3, PALETTE_TRIG = 4;
     public static final int BVH_WORLD = 0, BVH_ACTOR = 1;
     public static final int PEER_LOCAL = 0, PEER_DIRECT = 1, PEER_STAGED = 2;
+    public static final int TRANSPORT_PEER_COPY = 0, TRANSPORT_RCCL_SENDRECV = 1, TRANSPORT_RCCL_REDUCE = 2;
     public static final int OPT_DRAW_DEPTH = 0, OPT_MAX_DEPTH = 1, OPT_EMITTER_SCALE = 2, OPT_KERNEL = 3, OPT_SUN_SAMPLING = 4,
             OPT_EMITTERS = 5, OPT_BSDF = 6, OPT_EMITTER_NEE = 7, OPT_BVH_CULL_BEHIND = 8;
 }

@@ -84,7 +84,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path, single_rank_ima
     line = _run_bench(2, dump, launcher=False)
     coll = dict(line["collective"])
     assert len(coll.pop("readback_ms")) == 1
-    assert line["n_gpus"] == 2 and coll == {"backend": "gloo", "ranks": 2, "devices": [0], "launcher": "bench.py self-spawn"}
+    assert line["n_gpus"] == 2 and coll == {"backend": "gloo", "called_from": "torch.distributed", "ranks": 2, "devices": [0], "launcher": "bench.py self-spawn"}
     assert line["rccl_ranks"] == 0  # gloo rig: no RCCL ranks claimed
     np.testing.assert_array_equal(np.load(dump).view(np.uint32), want.view(np.uint32))
 
@@ -150,6 +150,35 @@ def test_group_mode_of_the_bench():
     assert line["image_check"]["bit_identical"], line["image_check"]
     e = line["end_to_end"]
     assert e["readbacks"] == 1 and e["value"] > 0 and e["cold_value"] > 0 and e["finite"], e
+    # two members on one device cannot share an RCCL communicator: the line says the exchange ran on peer copies, and why
+    c = line["collective"]
+    assert c["backend"] == "peer-copy" and c["called_from"].startswith("libchunky_hip") and "share device 0" in c["transport"]["detail"], c
+    assert line["rccl_ranks"] == 0 and line["readback"]["in_value"] and len(line["readback"]["to_host_ms"]) == 1
+
+
+def test_group_mode_of_the_bench_reports_rccl_from_the_library():
+    """`bench.py --group 1`: the one-member group has a real RCCL communicator, created by libchunky_hip itself (no torch.distributed
+    in the process): the line reports collective.backend "rccl" called from C++, as an 8-GPU group will."""
+    line = _run_single(["--group", "1"])
+    c = line["collective"]
+    assert c["backend"] == "rccl" and c["called_from"].startswith("libchunky_hip") and c["transport"]["name"] == "rccl-sendrecv", c
+    assert "rccl 2." in c["transport"]["detail"] and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    assert line["image_check"]["bit_identical"], line["image_check"]
+
+
+def test_default_line_times_every_baseline_config():
+    """The driver's command, shortened: the N = 1 default line carries `other_configs` — configs[1], [3], [4], each with its value,
+    launch time, contract roofline and an image check against the reference build's rows — and pays the read-back inside `value`."""
+    line = _run_single([])
+    legs = {o["baseline_config"]: o for o in line["other_configs"]}
+    assert sorted(legs) == [1, 3, 4], line["other_configs"]
+    for cfg, o in legs.items():
+        assert "error" not in o, o
+        assert o["value"] > 0 and o["launch_ms"] > 0 and o["steps"] >= 3 and o["image_check"]["bit_identical"], o
+        assert o["roofline"]["frac"] > 0 and o["roofline"]["bound"] == "hbm" and o["roofline"]["frac_above_one"] == (o["roofline"]["frac"] > 1), o["roofline"]
+    assert legs[4]["roofline"]["kernel"] == "render_pool<17,16,bvh>+fold_kernel"
+    rb = line["readback"]
+    assert rb["in_value"] and rb["count"] == 1 and rb["to_host_ms"][0] > 0 and line["value_hbm_resident"] >= line["value"]
 
 
 @pytest.mark.parametrize("config,kernel", [(1, "render_pool<17,56>+fold_kernel"), (3, "render_pool<17,56>+fold_kernel"), (4, "render_pool<17,16,bvh>+fold_kernel")])
