@@ -274,7 +274,10 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
 // A wave that wants paths of class X claims parked ones anywhere in the lot (an LDS compare-and-swap on the slot's tag makes
 // the slot its own for the exchange), trades its own lanes' paths for them with plain 16-byte reads and writes, and publishes
 // the new tags.  No wave ever waits for another: a lost claim is simply not swapped this round.
-DEV int lds_tag_load(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Ordering between the waves of a workgroup through LDS needs no wait: a wave's LDS instructions execute in program order, so a
+// record written before its tag is in the LDS before the tag is, and a record read after a successful compare-and-swap is read
+// after it.  Only the compiler has to keep that order (a workgroup-scope fence would also wait for every global store in flight).
+DEV void lds_compiler_fence() { asm volatile("" ::: "memory"); }
 template <int KS, int WORDS>
 DEV int pool_swap_shared(PoolLds P, LaneState& L, int& st, int X, int lane, int wave) {
     const bool done = st == ST_DONE;
@@ -288,7 +291,7 @@ DEV int pool_swap_shared(PoolLds P, LaneState& L, int& st, int X, int lane, int 
     const int jg = lane + 14 * wave < G ? lane + 14 * wave : lane + 14 * wave - G;
     int s = -1, seen = 0;
     if (lane < G) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (the other waves' tags: read them now, not from a register)
+        lds_compiler_fence();  // (the other waves' tags: read them now, not from a register)
         const int4 t = *((const int4*)P.tags + jg);
         if (phase_class(t.w) == X) s = 4 * jg + 3, seen = t.w;
         if (phase_class(t.z) == X) s = 4 * jg + 2, seen = t.z;
@@ -303,8 +306,9 @@ DEV int pool_swap_shared(PoolLds P, LaneState& L, int& st, int X, int lane, int 
     bool got = false;
     if (s >= 0 && r_in < n) {
         int expected = seen;
-        got = __hip_atomic_compare_exchange_strong(P.tags + s, &expected, ST_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        got = __hip_atomic_compare_exchange_strong(P.tags + s, &expected, ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    lds_compiler_fence();
     const LaneMask m_got = __ballot(got);
     const int n_got = __popcll(m_got);
     if (n_got == 0) return 0;
@@ -324,7 +328,8 @@ DEV int pool_swap_shared(PoolLds P, LaneState& L, int& st, int X, int lane, int 
 #pragma unroll
         for (int g = 0; g < WORDS; g++) P.park[g * KS + slot] = mine[g];
         // the record first, then the tag that hands the slot back to everybody
-        __hip_atomic_store(P.tags + slot, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_compiler_fence();
+        __hip_atomic_store(P.tags + slot, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         st = e >> 8;
         pool_unpack<WORDS>(L, theirs);
     }
@@ -338,7 +343,7 @@ struct LotCensus {
 template <int KS>
 DEV LotCensus lot_census(const int* tags, int lane) {
     int4 t = make_int4(ST_DONE, ST_DONE, ST_DONE, ST_DONE);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    lds_compiler_fence();
     if (lane < KS / 4) t = *((const int4*)tags + lane);
     LotCensus c;
     c.march = count_lanes(t.x == ST_MARCH) + count_lanes(t.y == ST_MARCH) + count_lanes(t.z == ST_MARCH) + count_lanes(t.w == ST_MARCH);
@@ -476,10 +481,10 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         P.list = P.tags + K;
         stacks.base = (int*)(base + K * 16 * WORDS + K * 8);
         if (BVH && lane < K) P.park[lane] = make_uint4(0u, 0u, (unsigned)(64 + lane) << 16, 0u);  // the parked slots' stack ids
-        if (WG) {  // one lot for the workgroup: [WORDS][KS] records, KS tags, then 64 ints of scratch per wave (same bytes in all)
+        if (WG) {  // one lot for the workgroup: [WORDS][KS] records, KS tags, then K ints of scratch per wave (the same bytes in all as without it)
             P.park = (uint4*)lds;
             P.tags = (int*)((char*)lds + KS * 16 * WORDS);
-            P.list = P.tags + KS + 64 * wave;
+            P.list = P.tags + KS + K * wave;  // (at most K lanes offer a slot per round; 26 880 bytes in all: six workgroups per CU)
             if (threadIdx.x < KS) P.tags[threadIdx.x] = ST_FRESH;
             __syncthreads();  // (the only barrier of the kernel: the lot's tags exist before anybody looks at them)
         }
@@ -557,6 +562,15 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                   v_shade = (c_shade < 64 ? c_shade : 64) * kWShade;
         int X = (v_shade >= v_block && v_shade >= v_march) ? 2 : (v_block >= v_march ? 1 : 0);
         int v_best = X == 2 ? v_shade : (X == 1 ? v_block : v_march);
+        int l_march = 0, l_block = 0, l_shade = 0;  // WG: the paths in this wave's lanes, by class
+        if (WG) {
+            // With a lot of 4 K slots nearly every class can fill the wave.  Among those that can, the one this wave already
+            // holds most of runs next: the fewest paths change hands.
+            l_march = count_lanes(st == ST_MARCH), l_block = count_lanes(st == ST_BLOCK), l_shade = count_lanes(st == ST_SHADE || st == ST_FRESH);
+            const int s_march = (c_march < 64 ? c_march : 64) * 64 + l_march, s_block = (c_block < 64 ? c_block : 64) * 64 + l_block,
+                      s_shade = (c_shade < 64 ? c_shade : 64) * 64 + l_shade;
+            X = (s_shade >= s_block && s_shade >= s_march) ? 2 : (s_block >= s_march ? 1 : 0);
+        }
         if (BVH) {  // the walk through the entity BVHs (inner-node and leaf visits together) is one class of the pool
             const int c_walk = c_bvh + c_leaf;
             const int v_walk = (c_walk < 64 ? c_walk : 64) * kWWalk;
@@ -570,7 +584,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                 n = pool_swap_shared<KS, WORDS>(P, L, st, X, lane, wave);
                 // The census was a snapshot: another wave may have taken the paths this one voted for.  If the lanes now hold
                 // clearly more paths of another class than of X, that class runs instead (no second exchange).
-                const int l_march = count_lanes(st == ST_MARCH), l_block = count_lanes(st == ST_BLOCK), l_shade = count_lanes(st == ST_SHADE || st == ST_FRESH);
+                l_march = count_lanes(st == ST_MARCH), l_block = count_lanes(st == ST_BLOCK), l_shade = count_lanes(st == ST_SHADE || st == ST_FRESH);
                 const int l_x = X == 0 ? l_march : (X == 1 ? l_block : l_shade);
                 int Y = (l_shade >= l_block && l_shade >= l_march) ? 2 : (l_block >= l_march ? 1 : 0);
                 const int l_y = Y == 0 ? l_march : (Y == 1 ? l_block : l_shade);
@@ -603,6 +617,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             // from the parked marchers.  One bound, fixed on entry: the loop's bookkeeping is one popcount and one compare.
             const int other_b = c_block < 64 ? c_block : 64, other_s = c_shade < 64 ? c_shade : 64;
             int other = other_b > other_s ? other_b : other_s;
+            if (WG) other = l_block > l_shade ? l_block : l_shade;  // (what waits in the lot is any wave's business: only this wave's own crowd counts)
             // (with entity BVHs the walkers are not counted: they are the pool's standing crowd and wait in any case)
             int stay = (other + nm + 1) >> 1;
             if (K > 0 && parked_march >= kPoolRefill && stay < 65 - kPoolRefill) stay = 65 - kPoolRefill;
@@ -867,6 +882,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
         if (tree != 17) tree = -1;
         park = kPoolPark;
         k = tree == 17 ? render_pool<17, kPoolPark, true> : render_pool<-1, kPoolPark, true>;
+        if (variant & 256) k = tree == 17 ? render_pool<17, kPoolPark, true, false, false, true> : render_pool<-1, kPoolPark, true, false, false, true>;
     } else if (park != kPoolPark) {
         if (tree != 0) tree = -1;
         if (park == 0) k = tree == 0 ? render_pool<0, 0, false> : render_pool<-1, 0, false>;
@@ -885,7 +901,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
         }
     }
     size_t lds = (size_t)(block / 64) * (size_t)(park * 16 * words + park * 8 + (64 + park) * depth * 4);
-    if ((variant & 256) && !bvh && !ext && !stats && park == kPoolPark) lds = (size_t)4 * park * 16 * words + (size_t)4 * park * 4 + 4 * 64 * 4;
+    if ((variant & 256) && !bvh && !ext && park == kPoolPark) lds = (size_t)4 * park * 16 * words + (size_t)4 * park * 4 + (size_t)4 * park * 4;
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
     if (e != hipSuccess) return e;
