@@ -270,75 +270,49 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
     wave_lds_fence();  // the next swap's readers (other lanes) come after these writes
     return n;
 }
-// ---- EXPERIMENT (round 5, variant bit 8), iteration 2: the parked paths of the FOUR waves of a workgroup sit in one lot of
-// KS = 4 K slots, a quarter per wave.  A wave trades with its OWN quarter first — the paths it parked itself, rays of its
-// own tiles — and tops the phase up with paths from the other quarters only when its own cannot fill the lanes.  A slot is
-// taken with an LDS compare-and-swap on its tag (ST_BUSY while the exchange runs), the records move with plain 16-byte
-// reads and writes, and the new tag hands the slot back.  No wave ever waits for another: a lost claim is not swapped this round.
-// Ordering between the waves of a workgroup through LDS needs no wait: a wave's LDS instructions execute in program order, so a
-// record written before its tag is in the LDS before the tag is, and a record read after a successful compare-and-swap is read
-// after it.  Only the compiler has to keep that order (a workgroup-scope fence would also wait for every global store in flight).
-DEV void lds_compiler_fence() { asm volatile("" ::: "memory"); }
-constexpr int kBorrowMin = 4;  // lanes that must be missing before a wave looks into the other quarters
-struct LotTags {
-    int own, f1, f2, f3;  // lane j < K: the tags of slot j of the wave's own quarter and of the three others (DONE for lanes >= K)
-};
-template <int K>
-DEV LotTags lot_tags(const int* tags, int lane, int wave) {
-    LotTags t{ST_DONE, ST_DONE, ST_DONE, ST_DONE};
-    lds_compiler_fence();
-    if (lane < K) {
-        t.own = tags[wave * K + lane];
-        t.f1 = tags[((wave + 1) & 3) * K + lane];
-        t.f2 = tags[((wave + 2) & 3) * K + lane];
-        t.f3 = tags[((wave + 3) & 3) * K + lane];
-    }
-    return t;
-}
-DEV bool lds_claim(int* tag, int seen) {
-    int expected = seen;
-    return __hip_atomic_compare_exchange_strong(tag, &expected, ST_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-template <int K, int WORDS>
-DEV int pool_swap_shared(PoolLds P, LaneState& L, int& st, int X, int lane, int wave, bool borrow) {
-    constexpr int KS = 4 * K;
+// ---- EXPERIMENT (round 5, variant bit 8): the parked paths of the FOUR waves of a workgroup form one lot of KS = 4 K slots.
+// A wave that wants paths of class X claims parked ones anywhere in the lot (an LDS compare-and-swap on the slot's tag makes
+// the slot its own for the exchange), trades its own lanes' paths for them with plain 16-byte reads and writes, and publishes
+// the new tags.  No wave ever waits for another: a lost claim is simply not swapped this round.
+DEV int lds_tag_load(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <int KS, int WORDS>
+DEV int pool_swap_shared(PoolLds P, LaneState& L, int& st, int X, int lane, int wave) {
     const bool done = st == ST_DONE;
     const bool out = phase_class(st) != X;
     const LaneMask m_done = __ballot(done), m_out = __ballot(out && !done);
     const int n_done = __popcll(m_done), n_out = n_done + __popcll(m_out);
     if (n_out == 0) return 0;  // wave-uniform
-    const LotTags t = lot_tags<K>(P.tags, lane, wave);
-    const bool own_has = phase_class(t.own) == X;
-    const LaneMask m_own = __ballot(own_has);
-    const int n_own = __popcll(m_own);
-    const int take_own = n_out < n_own ? n_out : n_own;
-    const int r_own = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_own >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_own, 0u));
-    // what the own quarter cannot supply comes from the others (slot j of the next quarter that has one)
-    int sf = -1, seen_f = 0;
-    const int missing = n_out - take_own;
-    if (borrow && missing >= kBorrowMin) {
-        if (phase_class(t.f3) == X) sf = ((wave + 3) & 3) * K + lane, seen_f = t.f3;
-        if (phase_class(t.f2) == X) sf = ((wave + 2) & 3) * K + lane, seen_f = t.f2;
-        if (phase_class(t.f1) == X) sf = ((wave + 1) & 3) * K + lane, seen_f = t.f1;
+    // lane j looks at slots 4 j' .. 4 j' + 3 (j' = j rotated by the wave's index, so that the waves of a workgroup do not all
+    // start their search at the same slots) and offers the first one that holds a path of class X
+    constexpr int G = KS / 4;  // groups of four slots
+    const int jg = lane + 14 * wave < G ? lane + 14 * wave : lane + 14 * wave - G;
+    int s = -1, seen = 0;
+    if (lane < G) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (the other waves' tags: read them now, not from a register)
+        const int4 t = *((const int4*)P.tags + jg);
+        if (phase_class(t.w) == X) s = 4 * jg + 3, seen = t.w;
+        if (phase_class(t.z) == X) s = 4 * jg + 2, seen = t.z;
+        if (phase_class(t.y) == X) s = 4 * jg + 1, seen = t.y;
+        if (phase_class(t.x) == X) s = 4 * jg, seen = t.x;
     }
-    const LaneMask m_for = __ballot(sf >= 0);
-    const int n_for = __popcll(m_for);
-    int take_for = missing < n_for ? missing : n_for;
-    if (take_for > K - take_own) take_for = K - take_own;  // (the wave's scratch list holds K entries)
-    if (take_own + take_for == 0) return 0;
-    const int r_for = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_for >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_for, 0u));
-    bool got_own = false, got_for = false;
-    if (own_has && r_own < take_own) got_own = lds_claim(P.tags + wave * K + lane, t.own);
-    if (sf >= 0 && r_for < take_for) got_for = lds_claim(P.tags + sf, seen_f);
-    lds_compiler_fence();
-    const LaneMask g_own = __ballot(got_own), g_for = __ballot(got_for);
-    const int n_got_own = __popcll(g_own), n_got = n_got_own + __popcll(g_for);
+    const LaneMask m_in = __ballot(s >= 0);
+    const int n_in = __popcll(m_in);
+    const int n = n_out < n_in ? n_out : n_in;
+    if (n == 0) return 0;
+    const int r_in = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_in, 0u));
+    bool got = false;
+    if (s >= 0 && r_in < n) {
+        int expected = seen;
+        got = __hip_atomic_compare_exchange_strong(P.tags + s, &expected, ST_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const LaneMask m_got = __ballot(got);
+    const int n_got = __popcll(m_got);
     if (n_got == 0) return 0;
-    if (got_own) P.list[(int)__builtin_amdgcn_mbcnt_hi((unsigned)(g_own >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)g_own, 0u))] = (wave * K + lane) | (t.own << 8);
-    if (got_for) P.list[n_got_own + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(g_for >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)g_for, 0u))] = sf | (seen_f << 8);
+    const int r_got = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_got >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_got, 0u));
     const LaneMask m_mine = done ? m_done : m_out;
     const int r_out = (done ? 0 : n_done) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_mine, 0u));
     const bool goes = out && r_out < n_got;
+    if (got) P.list[r_got] = s | (seen << 8);  // slot and tag of the r-th claimed path (the wave's own scratch)
     wave_lds_fence();
     if (goes) {
         const int e = P.list[r_out];
@@ -349,13 +323,30 @@ DEV int pool_swap_shared(PoolLds P, LaneState& L, int& st, int X, int lane, int 
         for (int g = 0; g < WORDS; g++) theirs[g] = P.park[g * KS + slot];
 #pragma unroll
         for (int g = 0; g < WORDS; g++) P.park[g * KS + slot] = mine[g];
-        lds_compiler_fence();  // the record first, then the tag that hands the slot back to everybody
-        __hip_atomic_store(P.tags + slot, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // the record first, then the tag that hands the slot back to everybody
+        __hip_atomic_store(P.tags + slot, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         st = e >> 8;
         pool_unpack<WORDS>(L, theirs);
     }
     wave_lds_fence();
     return n_got;
+}
+// the census of the lot: how many of its slots hold a path of each class (a snapshot: other waves keep trading)
+struct LotCensus {
+    int march, block, shade, busy;
+};
+template <int KS>
+DEV LotCensus lot_census(const int* tags, int lane) {
+    int4 t = make_int4(ST_DONE, ST_DONE, ST_DONE, ST_DONE);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < KS / 4) t = *((const int4*)tags + lane);
+    LotCensus c;
+    c.march = count_lanes(t.x == ST_MARCH) + count_lanes(t.y == ST_MARCH) + count_lanes(t.z == ST_MARCH) + count_lanes(t.w == ST_MARCH);
+    c.block = count_lanes(t.x == ST_BLOCK) + count_lanes(t.y == ST_BLOCK) + count_lanes(t.z == ST_BLOCK) + count_lanes(t.w == ST_BLOCK);
+    c.shade = count_lanes(t.x == ST_SHADE || t.x == ST_FRESH) + count_lanes(t.y == ST_SHADE || t.y == ST_FRESH) +
+              count_lanes(t.z == ST_SHADE || t.z == ST_FRESH) + count_lanes(t.w == ST_SHADE || t.w == ST_FRESH);
+    c.busy = count_lanes(t.x == ST_BUSY) + count_lanes(t.y == ST_BUSY) + count_lanes(t.z == ST_BUSY) + count_lanes(t.w == ST_BUSY);
+    return c;
 }
 
 // Tunables of the pool kernel (each measured on the bench; DESIGN.md section 5 has the sweeps).  The -D overrides exist
@@ -485,10 +476,10 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         P.list = P.tags + K;
         stacks.base = (int*)(base + K * 16 * WORDS + K * 8);
         if (BVH && lane < K) P.park[lane] = make_uint4(0u, 0u, (unsigned)(64 + lane) << 16, 0u);  // the parked slots' stack ids
-        if (WG) {  // one lot for the workgroup: [WORDS][KS] records, KS tags, then K ints of scratch per wave (the same bytes in all as without it)
+        if (WG) {  // one lot for the workgroup: [WORDS][KS] records, KS tags, then 64 ints of scratch per wave (same bytes in all)
             P.park = (uint4*)lds;
             P.tags = (int*)((char*)lds + KS * 16 * WORDS);
-            P.list = P.tags + KS + K * wave;  // (at most K lanes offer a slot per round; 26 880 bytes in all: six workgroups per CU)
+            P.list = P.tags + KS + 64 * wave;
             if (threadIdx.x < KS) P.tags[threadIdx.x] = ST_FRESH;
             __syncthreads();  // (the only barrier of the kernel: the lot's tags exist before anybody looks at them)
         }
@@ -543,24 +534,15 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         }
         // the pool's census: paths waiting for each phase, in lanes and parked
         int c_march, c_block, c_shade;
-        int f_march = 0, f_block = 0, f_shade = 0;  // WG: parked in the other waves' quarters
         if (WG) {
-            const LotTags t = lot_tags<K>(P.tags, lane, wave);
-            c_march = count_lanes(st == ST_MARCH) + count_lanes(t.own == ST_MARCH);
-            c_block = count_lanes(st == ST_BLOCK) + count_lanes(t.own == ST_BLOCK);
-            c_shade = count_lanes(st == ST_SHADE || st == ST_FRESH) + count_lanes(t.own == ST_SHADE || t.own == ST_FRESH);
-            f_march = count_lanes(t.f1 == ST_MARCH) + count_lanes(t.f2 == ST_MARCH) + count_lanes(t.f3 == ST_MARCH);
-            f_block = count_lanes(t.f1 == ST_BLOCK) + count_lanes(t.f2 == ST_BLOCK) + count_lanes(t.f3 == ST_BLOCK);
-            f_shade = count_lanes(t.f1 == ST_SHADE || t.f1 == ST_FRESH) + count_lanes(t.f2 == ST_SHADE || t.f2 == ST_FRESH) +
-                      count_lanes(t.f3 == ST_SHADE || t.f3 == ST_FRESH);
-            if ((c_march | c_block | c_shade) == 0) {  // nothing of its own left: the wave helps with what the others parked
-                const int busy = count_lanes(t.own == ST_BUSY) + count_lanes(t.f1 == ST_BUSY) + count_lanes(t.f2 == ST_BUSY) + count_lanes(t.f3 == ST_BUSY);
-                if ((f_march | f_block | f_shade) == 0) {
-                    if (busy == 0) break;  // nothing in this wave's lanes and nothing in the lot
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;              // a slot is changing hands: look again
-                }
-                c_march = f_march, c_block = f_block, c_shade = f_shade;  // (vote on them; the swap below borrows)
+            const LotCensus lot = lot_census<KS>(P.tags, lane);
+            c_march = count_lanes(st == ST_MARCH) + lot.march;
+            c_block = count_lanes(st == ST_BLOCK) + lot.block;
+            c_shade = count_lanes(st == ST_SHADE || st == ST_FRESH) + lot.shade;
+            if ((c_march | c_block | c_shade) == 0) {
+                if (lot.busy == 0) break;  // nothing in this wave's lanes and nothing in the lot
+                __builtin_amdgcn_s_sleep(2);
+                continue;                  // a slot is changing hands: look again
             }
         } else {
             c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
@@ -585,8 +567,14 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         if (K > 0) {
             int n;
             if (WG) {
-                const int f_x = X == 0 ? f_march : (X == 1 ? f_block : f_shade);
-                n = pool_swap_shared<K, WORDS>(P, L, st, X, lane, wave, f_x > 0);
+                n = pool_swap_shared<KS, WORDS>(P, L, st, X, lane, wave);
+                // The census was a snapshot: another wave may have taken the paths this one voted for.  If the lanes now hold
+                // clearly more paths of another class than of X, that class runs instead (no second exchange).
+                const int l_march = count_lanes(st == ST_MARCH), l_block = count_lanes(st == ST_BLOCK), l_shade = count_lanes(st == ST_SHADE || st == ST_FRESH);
+                const int l_x = X == 0 ? l_march : (X == 1 ? l_block : l_shade);
+                int Y = (l_shade >= l_block && l_shade >= l_march) ? 2 : (l_block >= l_march ? 1 : 0);
+                const int l_y = Y == 0 ? l_march : (Y == 1 ? l_block : l_shade);
+                if (l_y > l_x + 16) X = Y;
             } else {
                 n = pool_swap<K, WORDS>(P, L, st, ptag, X, lane);
             }
@@ -608,7 +596,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             const LaneMask entered = __ballot(st == ST_MARCH);
             int nm = __popcll(entered);
             n_exec = nm;
-            const int parked_march = c_march - nm + (WG ? f_march : 0);  // marchers still parked after the swap (WG: the other quarters' too)
+            const int parked_march = c_march - nm;  // marchers still parked after the swap
             // The wave stays in the march while it runs fuller than anything else could: lanes that leave join the paths
             // waiting for BLOCK or SHADE (`other` of them already), so it leaves once nm would drop below the larger of those
             // crowds — at worst every leaver joins it: nm < other + (n0 - nm) — or once enough lanes are free for a refill
@@ -644,9 +632,9 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_BLOCK) st = block_phase<TREE, END, false>(S, L);
         } else if (BVH && X == 5) {
-            // The walk: a path alternates between inner-node visits and leaf visits every few nodes, so the two are voted
-            // here, in a loop of their own (two counts per round) instead of through the pool's census.  The wave stays while
-            // the walkers outnumber what waits elsewhere, or until enough lanes are free for a refill from parked walkers.
+            // The walk: inner-node visits and triangle tests are one step function (rwalk_step: the same four 16-byte reads
+            // from one array or the other), so a walker is ST_BVH throughout and the loop below counts that one state.  The
+            // wave stays while enough walkers remain, or until enough lanes are free for a refill from parked walkers.
             const SceneView S = arg_copy(&fresh_args()->S);
             int nw = count_lanes(st == ST_BVH);
             n_exec = nw;
@@ -879,7 +867,6 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
         if (tree != 17) tree = -1;
         park = kPoolPark;
         k = tree == 17 ? render_pool<17, kPoolPark, true> : render_pool<-1, kPoolPark, true>;
-        if (variant & 256) k = tree == 17 ? render_pool<17, kPoolPark, true, false, false, true> : render_pool<-1, kPoolPark, true, false, false, true>;
     } else if (park != kPoolPark) {
         if (tree != 0) tree = -1;
         if (park == 0) k = tree == 0 ? render_pool<0, 0, false> : render_pool<-1, 0, false>;
@@ -898,7 +885,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
         }
     }
     size_t lds = (size_t)(block / 64) * (size_t)(park * 16 * words + park * 8 + (64 + park) * depth * 4);
-    if ((variant & 256) && !bvh && !ext && park == kPoolPark) lds = (size_t)4 * park * 16 * words + (size_t)4 * park * 4 + (size_t)4 * park * 4;
+    if ((variant & 256) && !bvh && !ext && !stats && park == kPoolPark) lds = (size_t)4 * park * 16 * words + (size_t)4 * park * 4 + 4 * 64 * 4;
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
     if (e != hipSuccess) return e;
