@@ -13,6 +13,10 @@ namespace chunky {
 struct PathStacks {
     int* base;
     int paths;  // 64 + K
+    // EXPERIMENT 5.2: the breadth-first tops of the two BVHs staged in LDS by the workgroup (null: every record comes from memory).
+    // Word k of top record r sits at top[4 r + ((k + (r >> 2)) & 3)]: lanes at different records of one 256-byte bank row then
+    // read different bank quads.
+    const int4* top = nullptr;
 };
 // A walker is at a node: an inner record (bvh_cur >= 0) or a position inside a leaf (bvh_cur < 0:
 // -1 - (triangle record << 6 | triangles left)).  One STEP of the walk is one inner-node visit or ONE triangle test;
@@ -59,8 +63,31 @@ DEV WalkWords rwalk_fetch(const SceneView& S, const LaneState& L) {
     w.r3 = p[3];  // (of a triangle only a hit needs this one; fetching it for inner nodes only measured 2 % slower)
     return w;
 }
+// ... and with the tops in LDS: the index of the walker's record there, or -1
+DEV int rwalk_top_index(const SceneView& S, int cur) {
+    if (cur < 0) return -1;
+    if (cur < S.lds_top_w) return cur;
+    const unsigned a = (unsigned)(cur - S.actor_base);
+    return a < (unsigned)S.lds_top_a ? S.lds_top_w + (int)a : -1;
+}
+DEV WalkWords rwalk_fetch_top(const SceneView& S, const LaneState& L, const int4* top) {
+    const int r = rwalk_top_index(S, L.bvh_cur);
+    WalkWords w;
+    if (r >= 0) {
+        const int4* q = top + 4 * r;
+        const int sw = r >> 2;
+        w.r0 = q[sw & 3], w.r1 = q[(sw + 1) & 3], w.r2 = q[(sw + 2) & 3], w.r3 = q[(sw + 3) & 3];
+    } else {
+        const int4* __restrict__ p = (const int4*)((const char*)S.bvh_rec + rwalk_record_at(S, L.bvh_cur));
+        w.r0 = p[0], w.r1 = p[1], w.r2 = p[2], w.r3 = p[3];
+    }
+    return w;
+}
 DEV int rwalk_apply(const SceneView& S, LaneState& L, PathStacks K, const WalkWords& W);
-DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) { return rwalk_apply(S, L, K, rwalk_fetch(S, L)); }
+template <bool TOP = false>
+DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) {
+    return rwalk_apply(S, L, K, TOP ? rwalk_fetch_top(S, L, K.top) : rwalk_fetch(S, L));
+}
 DEV int rwalk_apply(const SceneView& S, LaneState& L, PathStacks K, const WalkWords& W) {
     const int cur = L.bvh_cur;
     const bool inner = cur >= 0;

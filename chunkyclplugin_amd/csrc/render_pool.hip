@@ -164,9 +164,8 @@ struct PoolLds {
     int* list;    // [K] scratch: the slots taking part in a swap, by rank
 };
 
-constexpr int ST_BUSY = 13;  // (shared lot, experiment) a slot in the middle of an exchange: its record belongs to the wave that claimed it
 DEV int phase_class(int st) {
-    return st == ST_MARCH ? 0 : (st == ST_BLOCK ? 1 : (st == ST_DONE ? 3 : ((st == ST_BVH || st == ST_LEAF) ? 5 : (st == ST_BUSY ? 4 : 2))));
+    return st == ST_MARCH ? 0 : (st == ST_BLOCK ? 1 : (st == ST_DONE ? 3 : ((st == ST_BVH || st == ST_LEAF) ? 5 : 2)));
 }
 
 // A parked path is WORDS 16-byte words.  7 words without entity BVHs (the march-step count shares word 0 with the flags —
@@ -270,85 +269,6 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
     wave_lds_fence();  // the next swap's readers (other lanes) come after these writes
     return n;
 }
-// ---- EXPERIMENT (round 5, variant bit 8): the parked paths of the FOUR waves of a workgroup form one lot of KS = 4 K slots.
-// A wave that wants paths of class X claims parked ones anywhere in the lot (an LDS compare-and-swap on the slot's tag makes
-// the slot its own for the exchange), trades its own lanes' paths for them with plain 16-byte reads and writes, and publishes
-// the new tags.  No wave ever waits for another: a lost claim is simply not swapped this round.
-DEV int lds_tag_load(int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-template <int KS, int WORDS>
-DEV int pool_swap_shared(PoolLds P, LaneState& L, int& st, int X, int lane, int wave) {
-    const bool done = st == ST_DONE;
-    const bool out = phase_class(st) != X;
-    const LaneMask m_done = __ballot(done), m_out = __ballot(out && !done);
-    const int n_done = __popcll(m_done), n_out = n_done + __popcll(m_out);
-    if (n_out == 0) return 0;  // wave-uniform
-    // lane j looks at slots 4 j' .. 4 j' + 3 (j' = j rotated by the wave's index, so that the waves of a workgroup do not all
-    // start their search at the same slots) and offers the first one that holds a path of class X
-    constexpr int G = KS / 4;  // groups of four slots
-    const int jg = lane + 14 * wave < G ? lane + 14 * wave : lane + 14 * wave - G;
-    int s = -1, seen = 0;
-    if (lane < G) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (the other waves' tags: read them now, not from a register)
-        const int4 t = *((const int4*)P.tags + jg);
-        if (phase_class(t.w) == X) s = 4 * jg + 3, seen = t.w;
-        if (phase_class(t.z) == X) s = 4 * jg + 2, seen = t.z;
-        if (phase_class(t.y) == X) s = 4 * jg + 1, seen = t.y;
-        if (phase_class(t.x) == X) s = 4 * jg, seen = t.x;
-    }
-    const LaneMask m_in = __ballot(s >= 0);
-    const int n_in = __popcll(m_in);
-    const int n = n_out < n_in ? n_out : n_in;
-    if (n == 0) return 0;
-    const int r_in = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_in, 0u));
-    bool got = false;
-    if (s >= 0 && r_in < n) {
-        int expected = seen;
-        got = __hip_atomic_compare_exchange_strong(P.tags + s, &expected, ST_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    const LaneMask m_got = __ballot(got);
-    const int n_got = __popcll(m_got);
-    if (n_got == 0) return 0;
-    const int r_got = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_got >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_got, 0u));
-    const LaneMask m_mine = done ? m_done : m_out;
-    const int r_out = (done ? 0 : n_done) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_mine, 0u));
-    const bool goes = out && r_out < n_got;
-    if (got) P.list[r_got] = s | (seen << 8);  // slot and tag of the r-th claimed path (the wave's own scratch)
-    wave_lds_fence();
-    if (goes) {
-        const int e = P.list[r_out];
-        const int slot = e & 0xFF;
-        uint4 mine[WORDS], theirs[WORDS];
-        pool_pack<WORDS>(L, mine);
-#pragma unroll
-        for (int g = 0; g < WORDS; g++) theirs[g] = P.park[g * KS + slot];
-#pragma unroll
-        for (int g = 0; g < WORDS; g++) P.park[g * KS + slot] = mine[g];
-        // the record first, then the tag that hands the slot back to everybody
-        __hip_atomic_store(P.tags + slot, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        st = e >> 8;
-        pool_unpack<WORDS>(L, theirs);
-    }
-    wave_lds_fence();
-    return n_got;
-}
-// the census of the lot: how many of its slots hold a path of each class (a snapshot: other waves keep trading)
-struct LotCensus {
-    int march, block, shade, busy;
-};
-template <int KS>
-DEV LotCensus lot_census(const int* tags, int lane) {
-    int4 t = make_int4(ST_DONE, ST_DONE, ST_DONE, ST_DONE);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane < KS / 4) t = *((const int4*)tags + lane);
-    LotCensus c;
-    c.march = count_lanes(t.x == ST_MARCH) + count_lanes(t.y == ST_MARCH) + count_lanes(t.z == ST_MARCH) + count_lanes(t.w == ST_MARCH);
-    c.block = count_lanes(t.x == ST_BLOCK) + count_lanes(t.y == ST_BLOCK) + count_lanes(t.z == ST_BLOCK) + count_lanes(t.w == ST_BLOCK);
-    c.shade = count_lanes(t.x == ST_SHADE || t.x == ST_FRESH) + count_lanes(t.y == ST_SHADE || t.y == ST_FRESH) +
-              count_lanes(t.z == ST_SHADE || t.z == ST_FRESH) + count_lanes(t.w == ST_SHADE || t.w == ST_FRESH);
-    c.busy = count_lanes(t.x == ST_BUSY) + count_lanes(t.y == ST_BUSY) + count_lanes(t.z == ST_BUSY) + count_lanes(t.w == ST_BUSY);
-    return c;
-}
-
 // Tunables of the pool kernel (each measured on the bench; DESIGN.md section 5 has the sweeps).  The -D overrides exist
 // for tuning builds (tools/variants.sh) only.
 #ifndef CHUNKY_POOL_WAVES
@@ -457,11 +377,9 @@ DEV void march_loop(const SceneView& Sm, const RenderOpts& Om, LaneState& L, Lan
     } while (nm >= stay);
 }
 
-template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false, bool WG = false>
+template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false>
 __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
-    static_assert(!WG || (!BVH && !EXT && K % 4 == 0 && 4 * K < 256), "the shared lot exists for the plain integrator without entity BVHs");
     constexpr int WORDS = EXT ? 9 : (BVH ? 8 : 7);  // 16-byte words of a parked path (pool_pack)
-    constexpr int KS = 4 * K;                        // WG: slots of the workgroup's lot
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -476,13 +394,6 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         P.list = P.tags + K;
         stacks.base = (int*)(base + K * 16 * WORDS + K * 8);
         if (BVH && lane < K) P.park[lane] = make_uint4(0u, 0u, (unsigned)(64 + lane) << 16, 0u);  // the parked slots' stack ids
-        if (WG) {  // one lot for the workgroup: [WORDS][KS] records, KS tags, then 64 ints of scratch per wave (same bytes in all)
-            P.park = (uint4*)lds;
-            P.tags = (int*)((char*)lds + KS * 16 * WORDS);
-            P.list = P.tags + KS + 64 * wave;
-            if (threadIdx.x < KS) P.tags[threadIdx.x] = ST_FRESH;
-            __syncthreads();  // (the only barrier of the kernel: the lot's tags exist before anybody looks at them)
-        }
     }
     LdsStack stack{lds, 0};  // render_waves' per-lane stacks are not used here
     LaneState L;
@@ -533,25 +444,12 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             if (st == ST_TRACED) st = rbvh_begin(S, L);
         }
         // the pool's census: paths waiting for each phase, in lanes and parked
-        int c_march, c_block, c_shade;
-        if (WG) {
-            const LotCensus lot = lot_census<KS>(P.tags, lane);
-            c_march = count_lanes(st == ST_MARCH) + lot.march;
-            c_block = count_lanes(st == ST_BLOCK) + lot.block;
-            c_shade = count_lanes(st == ST_SHADE || st == ST_FRESH) + lot.shade;
-            if ((c_march | c_block | c_shade) == 0) {
-                if (lot.busy == 0) break;  // nothing in this wave's lanes and nothing in the lot
-                __builtin_amdgcn_s_sleep(2);
-                continue;                  // a slot is changing hands: look again
-            }
-        } else {
-            c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
-            c_block = count_lanes(st == ST_BLOCK) + count_lanes(ptag == ST_BLOCK);
-            c_shade = count_lanes(st == ST_SHADE || st == ST_FRESH) + count_lanes(ptag == ST_SHADE || ptag == ST_FRESH);
-        }
+        const int c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
+        const int c_block = count_lanes(st == ST_BLOCK) + count_lanes(ptag == ST_BLOCK);
+        const int c_shade = count_lanes(st == ST_SHADE || st == ST_FRESH) + count_lanes(ptag == ST_SHADE || ptag == ST_FRESH);
         const int c_bvh = BVH ? count_lanes(st == ST_BVH) + count_lanes(ptag == ST_BVH) : 0;
         const int c_leaf = BVH ? count_lanes(st == ST_LEAF) + count_lanes(ptag == ST_LEAF) : 0;
-        if (!WG && (c_march | c_block | c_shade | c_bvh | c_leaf) == 0) break;  // every lane and every slot is ST_DONE
+        if ((c_march | c_block | c_shade | c_bvh | c_leaf) == 0) break;  // every lane and every slot is ST_DONE
         // at most 64 paths run at once; among phases that can fill the wave SHADE and BLOCK go first (they feed the march)
         const int v_march = (c_march < 64 ? c_march : 64) * kWMarch, v_block = (c_block < 64 ? c_block : 64) * kWBlock,
                   v_shade = (c_shade < 64 ? c_shade : 64) * kWShade;
@@ -565,19 +463,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_amdgcn_s_memtime();
         if (K > 0) {
-            int n;
-            if (WG) {
-                n = pool_swap_shared<KS, WORDS>(P, L, st, X, lane, wave);
-                // The census was a snapshot: another wave may have taken the paths this one voted for.  If the lanes now hold
-                // clearly more paths of another class than of X, that class runs instead (no second exchange).
-                const int l_march = count_lanes(st == ST_MARCH), l_block = count_lanes(st == ST_BLOCK), l_shade = count_lanes(st == ST_SHADE || st == ST_FRESH);
-                const int l_x = X == 0 ? l_march : (X == 1 ? l_block : l_shade);
-                int Y = (l_shade >= l_block && l_shade >= l_march) ? 2 : (l_block >= l_march ? 1 : 0);
-                const int l_y = Y == 0 ? l_march : (Y == 1 ? l_block : l_shade);
-                if (l_y > l_x + 16) X = Y;
-            } else {
-                n = pool_swap<K, WORDS>(P, L, st, ptag, X, lane);
-            }
+            const int n = pool_swap<K, WORDS>(P, L, st, ptag, X, lane);
             if (STATS && n) {
                 swap_rounds += 1;
                 swapped += (unsigned long long)n;
@@ -871,9 +757,6 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
         if (tree != 0) tree = -1;
         if (park == 0) k = tree == 0 ? render_pool<0, 0, false> : render_pool<-1, 0, false>;
         else k = tree == 0 ? render_pool<0, 32, false> : render_pool<-1, 32, false>;
-    } else if (variant & 256) {  // EXPERIMENT: the workgroup's parked paths as one shared lot
-        if (tree != 17) tree = -1;
-        k = tree == 17 ? render_pool<17, kPoolPark, false, false, false, true> : render_pool<-1, kPoolPark, false, false, false, true>;
     } else {
         switch (tree) {
             case 0: k = render_pool<0, kPoolPark, false>; break;
@@ -885,7 +768,6 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
         }
     }
     size_t lds = (size_t)(block / 64) * (size_t)(park * 16 * words + park * 8 + (64 + park) * depth * 4);
-    if ((variant & 256) && !bvh && !ext && !stats && park == kPoolPark) lds = (size_t)4 * park * 16 * words + (size_t)4 * park * 4 + 4 * 64 * 4;
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
     if (e != hipSuccess) return e;
