@@ -74,9 +74,14 @@ DEV WalkWords rwalk_fetch_top(const SceneView& S, const LaneState& L, const int4
     const int r = rwalk_top_index(S, L.bvh_cur);
     WalkWords w;
     if (r >= 0) {
-        const int4* q = top + 4 * r;
+        // (an explicit LDS pointer: with a generic one the compiler merges both sides into thirteen 4-byte flat loads)
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        typedef const v4i __attribute__((address_space(3))) * LdsWords;
+        LdsWords q = (LdsWords)(const v4i*)top + 4 * r;
         const int sw = r >> 2;
-        w.r0 = q[sw & 3], w.r1 = q[(sw + 1) & 3], w.r2 = q[(sw + 2) & 3], w.r3 = q[(sw + 3) & 3];
+        const v4i a = q[sw & 3], b = q[(sw + 1) & 3], c = q[(sw + 2) & 3], d = q[(sw + 3) & 3];
+        w.r0 = make_int4(a.x, a.y, a.z, a.w), w.r1 = make_int4(b.x, b.y, b.z, b.w);
+        w.r2 = make_int4(c.x, c.y, c.z, c.w), w.r3 = make_int4(d.x, d.y, d.z, d.w);
     } else {
         const int4* __restrict__ p = (const int4*)((const char*)S.bvh_rec + rwalk_record_at(S, L.bvh_cur));
         w.r0 = p[0], w.r1 = p[1], w.r2 = p[2], w.r3 = p[3];

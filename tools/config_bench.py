@@ -32,6 +32,8 @@ def run(sc, name, passes=32, launches=3, world=1, ext=None, check_rows=(60, 250,
     r = HipPathTracingRenderer(loader, sc.width, sc.height)
     r.set_camera(sc.projector_type, sc.camera)
     r.set_shard(0, world, 0)   # 16 x 16-pixel blocks, as bench.py --gpus N
+    if os.environ.get("CHUNKY_BENCH_KERNEL"):   # tuning runs: an experimental kernel variant (CHUNKY_OPT_KERNEL)
+        r.set_option(native.OPT_KERNEL, int(os.environ["CHUNKY_BENCH_KERNEL"]))
     for k, v in (ext or {}).items():
         r.set_option({"nee": native.OPT_EMITTER_NEE, "bsdf": native.OPT_BSDF, "cull": native.OPT_BVH_CULL_BEHIND}[k], v)
     seeds = native.java_random_ints(passes * (launches + 1))
