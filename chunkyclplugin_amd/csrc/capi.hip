@@ -106,7 +106,6 @@ struct chunky_scene {
     bool emitters_dirty = true;
     std::vector<int32_t> host_trigs, host_world_bvh, host_actor_bvh;
     int world_root = 0, actor_root = 0;                // first reference of each BVH in bvh_rec / tri_rec (rt_device.hpp)
-    int lds_top_w = 0, lds_top_a = 0, actor_base = 0;  // experiment 5.2 (SceneView)
     bool bvh_dirty = false;
     std::vector<int32_t> host_blocks, host_materials, host_aabbs, host_quads;  // kept to rebuild what is derived from them
     bool derived_dirty = false;                        // block_info, quad_aux, mat8, aabb_rec, quad_rec
@@ -964,7 +963,7 @@ static void bvh_layout_params(int* top, int* treelet) {
 }
 
 static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_rec, std::vector<int32_t>* tri_rec, int* world_root,
-                              int* actor_root, int* lds_tops = nullptr) {
+                              int* actor_root) {
     const std::vector<int32_t>&T = s->host_trigs, &M = s->host_materials;
     const size_t n_mats = M.size() / 6;
     std::vector<int64_t> leaf_at(T.size(), -1);  // triangle pointer -> its leaf reference (leaves may be shared)
@@ -1039,22 +1038,6 @@ static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_r
     // where the records sit (addresses only: the walk's order, tests and arithmetic do not see it)
     int top = 0, treelet = 0;
     bvh_layout_params(&top, &treelet);
-    if (lds_tops) lds_tops[0] = lds_tops[1] = 0, lds_tops[2] = (int)world_records;
-    if (const char* e = getenv("CHUNKY_BVH_LDS_TOP")) {  // EXPERIMENT 5.2: "w,a" records of each BVH's breadth-first top go first
-        int w = 0, a = 0;
-        if (lds_tops && sscanf(e, "%d,%d", &w, &a) == 2 && w >= 0 && a >= 0 && w + a > 0 && w + a <= 2048) {
-            const size_t n_w = world_records, n_a = bvh_rec->size() / 16 - world_records;
-            if ((size_t)w > n_w) w = (int)n_w;
-            if ((size_t)a > n_a) a = (int)n_a;
-            if (*world_root < 0) w = 0;  // (a BVH whose root is a leaf has no inner record)
-            if (*actor_root < 0) a = 0;
-            relayout_bvh_records(bvh_rec, 0, world_records, world_root, w, 8);
-            relayout_bvh_records(bvh_rec, world_records, bvh_rec->size() / 16, actor_root, a, 8);
-            reorder_triangles(bvh_rec, tri_rec, world_root, actor_root);
-            lds_tops[0] = w, lds_tops[1] = a;
-            return true;
-        }
-    }
     if (treelet > 1) {
         relayout_bvh_records(bvh_rec, 0, world_records, world_root, top, treelet);
         relayout_bvh_records(bvh_rec, world_records, bvh_rec->size() / 16, actor_root, top, treelet);
@@ -1193,10 +1176,7 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
             !bvh_leaves_sound(s->host_actor_bvh, s->actor_empty, s->host_trigs, s->host_materials))
             return fail(CHUNKY_E_INVALID, "an entity BVH leaf or a triangle's material lies outside its palette");
         std::vector<int32_t> nodes, tris;
-        int tops[3] = {0, 0, 0};
-        s->lds_top_w = s->lds_top_a = s->actor_base = 0;
-        if ((!s->world_empty || !s->actor_empty) && build_bvh_records(s, &nodes, &tris, &s->world_root, &s->actor_root, tops)) {
-            s->lds_top_w = tops[0], s->lds_top_a = tops[1], s->actor_base = tops[2];
+        if ((!s->world_empty || !s->actor_empty) && build_bvh_records(s, &nodes, &tris, &s->world_root, &s->actor_root)) {
             if (nodes.empty()) nodes.resize(16, 0);  // both roots are leaves
             tris.resize(tris.size() + 20, 0);        // a step at the end of the last leaf reads one record past it
             // ONE allocation — nodes, then triangles — so the walk addresses either kind of record as a 32-bit byte offset off
@@ -1217,9 +1197,6 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     v->tri_off = (unsigned)s->tri_off;
     v->world_root = s->world_root;
     v->actor_root = s->actor_root;
-    v->lds_top_w = s->bvh_rec.p ? s->lds_top_w : 0;
-    v->lds_top_a = s->bvh_rec.p ? s->lds_top_a : 0;
-    v->actor_base = s->actor_base;
     v->quad_aux = (const float*)s->quad_aux.p;
     v->bvh_stack_entries = (s->world_height > s->actor_height ? s->world_height : s->actor_height) + 1;
     v->block_info = (const int4*)s->block_info.p;

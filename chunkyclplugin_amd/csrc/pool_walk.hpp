@@ -13,10 +13,6 @@ namespace chunky {
 struct PathStacks {
     int* base;
     int paths;  // 64 + K
-    // EXPERIMENT 5.2: the breadth-first tops of the two BVHs staged in LDS by the workgroup (null: every record comes from memory).
-    // Word k of top record r sits at top[4 r + ((k + (r >> 2)) & 3)]: lanes at different records of one 256-byte bank row then
-    // read different bank quads.
-    const int4* top = nullptr;
 };
 // A walker is at a node: an inner record (bvh_cur >= 0) or a position inside a leaf (bvh_cur < 0:
 // -1 - (triangle record << 6 | triangles left)).  One STEP of the walk is one inner-node visit or ONE triangle test;
@@ -63,36 +59,8 @@ DEV WalkWords rwalk_fetch(const SceneView& S, const LaneState& L) {
     w.r3 = p[3];  // (of a triangle only a hit needs this one; fetching it for inner nodes only measured 2 % slower)
     return w;
 }
-// ... and with the tops in LDS: the index of the walker's record there, or -1
-DEV int rwalk_top_index(const SceneView& S, int cur) {
-    if (cur < 0) return -1;
-    if (cur < S.lds_top_w) return cur;
-    const unsigned a = (unsigned)(cur - S.actor_base);
-    return a < (unsigned)S.lds_top_a ? S.lds_top_w + (int)a : -1;
-}
-DEV WalkWords rwalk_fetch_top(const SceneView& S, const LaneState& L, const int4* top) {
-    const int r = rwalk_top_index(S, L.bvh_cur);
-    WalkWords w;
-    if (r >= 0) {
-        // (an explicit LDS pointer: with a generic one the compiler merges both sides into thirteen 4-byte flat loads)
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        typedef const v4i __attribute__((address_space(3))) * LdsWords;
-        LdsWords q = (LdsWords)(const v4i*)top + 4 * r;
-        const int sw = r >> 2;
-        const v4i a = q[sw & 3], b = q[(sw + 1) & 3], c = q[(sw + 2) & 3], d = q[(sw + 3) & 3];
-        w.r0 = make_int4(a.x, a.y, a.z, a.w), w.r1 = make_int4(b.x, b.y, b.z, b.w);
-        w.r2 = make_int4(c.x, c.y, c.z, c.w), w.r3 = make_int4(d.x, d.y, d.z, d.w);
-    } else {
-        const int4* __restrict__ p = (const int4*)((const char*)S.bvh_rec + rwalk_record_at(S, L.bvh_cur));
-        w.r0 = p[0], w.r1 = p[1], w.r2 = p[2], w.r3 = p[3];
-    }
-    return w;
-}
 DEV int rwalk_apply(const SceneView& S, LaneState& L, PathStacks K, const WalkWords& W);
-template <bool TOP = false>
-DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) {
-    return rwalk_apply(S, L, K, TOP ? rwalk_fetch_top(S, L, K.top) : rwalk_fetch(S, L));
-}
+DEV int rwalk_step(const SceneView& S, LaneState& L, PathStacks K) { return rwalk_apply(S, L, K, rwalk_fetch(S, L)); }
 DEV int rwalk_apply(const SceneView& S, LaneState& L, PathStacks K, const WalkWords& W) {
     const int cur = L.bvh_cur;
     const bool inner = cur >= 0;

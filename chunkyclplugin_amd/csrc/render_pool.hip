@@ -377,10 +377,8 @@ DEV void march_loop(const SceneView& Sm, const RenderOpts& Om, LaneState& L, Lan
     } while (nm >= stay);
 }
 
-// EXPERIMENT 5.2 (TOP): ONE workgroup of 16 waves per CU, the breadth-first tops of the entity BVHs staged in its LDS.
-template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false, bool TOP = false>
-__global__ void __launch_bounds__(TOP ? 1024 : 256, TOP ? 4 : ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
-    static_assert(!TOP || (BVH && !EXT && !STATS), "the LDS top exists for the plain entity walk");
+template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false>
+__global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
     constexpr int WORDS = EXT ? 9 : (BVH ? 8 : 7);  // 16-byte words of a parked path (pool_pack)
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
@@ -390,21 +388,7 @@ __global__ void __launch_bounds__(TOP ? 1024 : 256, TOP ? 4 : ((STATS || EXT) ? 
     {
         // per wave: K parked records, their tag / list scratch, then (BVH) one to-visit stack per path of the pool
         const unsigned depth = BVH ? fresh_args()->stack_bytes : 0u;  // entries per stack
-        unsigned top_bytes = 0;
-        if (TOP) {  // the tops come first: records [0, lds_top_w) of the world BVH, then [actor_base, actor_base + lds_top_a)
-            const SceneView S0 = arg_copy(&fresh_args()->S);
-            const int n_top = S0.lds_top_w + S0.lds_top_a;
-            top_bytes = (unsigned)n_top * 64u;
-            int4* top = (int4*)lds;
-            for (int i = (int)threadIdx.x; i < 4 * n_top; i += (int)blockDim.x) {
-                const int r = i >> 2, k = i & 3;
-                const int src = r < S0.lds_top_w ? r : S0.actor_base + (r - S0.lds_top_w);
-                top[4 * r + ((k + (r >> 2)) & 3)] = S0.bvh_rec[4 * (size_t)src + k];
-            }
-            stacks.top = top;
-            __syncthreads();  // (the only barrier of the kernel)
-        }
-        char* base = (char*)lds + top_bytes + wave * (K * 16 * WORDS + K * 8 + (64 + K) * depth * 4);
+        char* base = (char*)lds + wave * (K * 16 * WORDS + K * 8 + (64 + K) * depth * 4);
         P.park = (uint4*)base;
         P.tags = (int*)(base + K * 16 * WORDS);
         P.list = P.tags + K;
@@ -556,7 +540,7 @@ __global__ void __launch_bounds__(TOP ? 1024 : 256, TOP ? 4 : ((STATS || EXT) ? 
                     prof[3] += 1;
                     prof[4] += (unsigned long long)nw;
                 }
-                if (st == ST_BVH) st = rwalk_step<TOP>(S, L, stacks);
+                if (st == ST_BVH) st = rwalk_step(S, L, stacks);
                 nw = count_lanes(st == ST_BVH);
             } while (nw >= stay);
             if (STATS) {
@@ -725,8 +709,7 @@ __global__ void __launch_bounds__(256) clear_foreign_kernel(ShardView T, int wid
 static hipError_t launch_pool(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                               const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
                               float* staging, const int* seeds_dev) {
-    int block = 256;
-    bool top_lds = false;
+    const int block = 256;
     int n_cu = 0;
     if (hipError_t e = current_device_cus(&n_cu)) return e;
     if (T.n_local <= 0 || P.n <= 0) return hipSuccess;
@@ -761,11 +744,6 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
             if (tree != 17) tree = -1;
             park = 16;
             k = tree == 17 ? render_pool<17, 16, true, true> : render_pool<-1, 16, true, true>;
-        } else if ((variant & 512) && S.lds_top_w + S.lds_top_a > 0) {  // EXPERIMENT 5.2: 16 waves per CU in one workgroup, BVH tops in LDS
-            if (tree != 17) tree = -1;
-            park = 16;
-            top_lds = true;
-            k = tree == 17 ? render_pool<17, 16, false, true, false, true> : render_pool<-1, 16, false, true, false, true>;
         } else if (park == 32) {
             k = tree == 17 ? render_pool<17, 32, false, true> : (tree == 18 ? render_pool<18, 32, false, true> : render_pool<-1, 32, false, true>);
         } else {
@@ -789,14 +767,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
             default: tree = -1; k = render_pool<-1, kPoolPark, false>; break;
         }
     }
-    if (top_lds) block = 1024;
     size_t lds = (size_t)(block / 64) * (size_t)(park * 16 * words + park * 8 + (64 + park) * depth * 4);
-    if (top_lds) {
-        lds += (size_t)(S.lds_top_w + S.lds_top_a) * 64;
-        if (lds > 160 * 1024) return hipErrorInvalidValue;  // (the tuning run asked for more top records than fit beside the pools)
-    }
-    if (top_lds)  // (more than 64 KB of dynamic LDS has to be asked for)
-        if (hipError_t ea = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return ea;
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
     if (e != hipSuccess) return e;

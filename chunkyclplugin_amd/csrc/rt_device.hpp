@@ -95,9 +95,6 @@ struct SceneView {
     const int4* __restrict__ tri_rec;  // = bvh_rec + tri_off bytes: one allocation, so either kind of record is a 32-bit offset off one base
     unsigned tri_off;
     int world_root, actor_root;  // reference of each BVH's root
-    // EXPERIMENT 5.2: the first lds_top_w records of the world BVH and the first lds_top_a of the actor BVH (which starts at record
-    // actor_base) are the breadth-first tops of their trees; a kernel that stages them in LDS serves walkers inside them from there
-    int lds_top_w, lds_top_a, actor_base;
     // emitter next-event estimation (extension): every emitter leaf of the octree as {x, y, z, level << 25 | block pointer},
     // in pre-order — the list of oracle/port.c port_list_emitters
     const int4* __restrict__ emitters;
