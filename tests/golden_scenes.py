@@ -69,7 +69,7 @@ def input_digest(sc: scenes.PackedScene) -> str:
 
 
 # ---- the BASELINE views at the sizes that are timed (tests/golden/timed_rows.npz: rows rendered by the reference build) ----
-TIMED_PASSES = 4
+TIMED_PASSES = 8
 TIMED_VIEWS = ["city", "city_entities", "outdoor", "indoor", "entities", "entities4k"]
 
 
@@ -94,9 +94,9 @@ def timed_view(name: str) -> scenes.PackedScene:
 
 
 def timed_rows(sc: scenes.PackedScene):
-    """Four whole rows per view: near the top, two in the middle (horizon / terrain), one near the bottom."""
+    """Sixteen whole rows per view, evenly spread from sky to foreground (30 720 pixels of a 1920-wide view, 61 440 at 3840)."""
     h = sc.height
-    return [h // 9, (4 * h) // 9 + 1, (5 * h) // 8, h - 7]
+    return [((2 * k + 1) * h) // 32 for k in range(16)]
 
 
 # ---- helper-level known answers (tests/golden/helpers.npz: the reference object's own helpers on these rows) ----

@@ -23,11 +23,11 @@ def test_image_check_compares_whole_rows_bit_for_bit():
     gold = bench.golden_rows("outdoor")
     assert gold is not None and bench.golden_rows("no such view") is None and bench.golden_rows(None) is None
     seeds, rows, want = gold
-    assert len(seeds) == 4 and want.shape == (len(rows), 1920, 3)
+    assert len(seeds) == 8 and len(rows) == 16 and want.shape == (len(rows), 1920, 3)
     img = np.zeros((1080, 1920, 3), np.float32)
     img[np.asarray(rows)] = want
     ok = bench.compare_golden(img.reshape(-1), gold, 1920)
-    assert ok["bit_identical"] and ok["pixels"] == 4 * 1920 and ok["pixels_differing"] == 0 and ok["max_rel_err"] == 0.0
+    assert ok["bit_identical"] and ok["pixels"] == 16 * 1920 and ok["pixels_differing"] == 0 and ok["max_rel_err"] == 0.0
     img[int(rows[2]), 77, 1] = np.nextafter(img[int(rows[2]), 77, 1], np.float32(2))   # one ulp in one channel of one pixel
     bad = bench.compare_golden(img.reshape(-1), gold, 1920)
     assert not bad["bit_identical"] and bad["pixels_differing"] == 1 and 0 < bad["max_rel_err"] < 1e-6

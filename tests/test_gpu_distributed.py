@@ -124,7 +124,7 @@ def test_headline_line_checks_its_own_image(tmp_path):
     line = _run_bench(2, str(tmp_path / "fb_full.npy"), small=False)
     assert line["config"]["baseline_config"] == 2 and line["config"]["passes_per_step"] == 256
     chk = line["image_check"]
-    assert chk["bit_identical"] and chk["pixels"] == 4 * 1920 and chk["pixels_differing"] == 0, chk
+    assert chk["bit_identical"] and chk["pixels"] == 16 * 1920 and chk["passes"] == 8 and chk["pixels_differing"] == 0, chk
     # and rank 0 then opened "all GPUs" behind one context (here: two members on GPU 0) while rank 1 waited on the store
     g = line["group_check"]
     assert "error" not in g, g
