@@ -610,8 +610,9 @@ def main():
                            "value": round(n_pix * args.steps * passes / dt2 / 1e6, 3), "unit": "Msamples/s",
                            "launch_ms": round(ms2 / max(n2, 1), 4), "image_check": check2,
                            "note": "the reference's walk visits every box the ray's LINE pierces, half of them behind the origin; with the "
-                                   "option those count as missed.  Identical to the reference build's rows here, but not the reference's "
-                                   "result by construction (EXPERIMENTS.md 4.4): `value` above is the reference's walk"}
+                                   "option those count as missed.  Identical to the reference build's rows here, but NOT the reference's "
+                                   "result in general (40 of 10^8 grazing traces on grid-aligned boxes differ, EXPERIMENTS.md 5.3): "
+                                   "`value` above is the reference's walk"}
         if world > 1:
             dist.barrier(group=ctl)
 

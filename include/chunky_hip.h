@@ -172,9 +172,10 @@ typedef enum chunky_option {
      * (the far end of the slab test is negative) counts as missed.  The reference's quick test (K/primitives.h:30-48, used by
      * K/bvh.h:72-85) has no such exit: it descends into every box the ray's LINE pierces, and about half of its node visits and
      * triangle tests are spent behind the origin (EXPERIMENTS.md 4.4).  A triangle there can only be "hit" when rounding noise
-     * carries its barycentric test across (the reference admits |det| down to 5e-6), so the image is the reference's wherever the
-     * reference's own arithmetic is meaningful — no trace of 41 million differed — but it is not the reference's BY CONSTRUCTION,
-     * which is why this is an option and 0 the default.  Specification: oracle/port.c with port_set_bvh_cull(1). */
+     * carries its barycentric test across, and that DOES happen: with entity boxes on the block grid and a bounce origin within a
+     * few ulps of a box edge, the reference accepts a hit the culled walk never tests — 40 of 10^8 adversarial traces
+     * (EXPERIMENTS.md 5.3, tests/test_bvh_cull.py).  Whole frames are usually identical to the reference's, single pixels
+     * occasionally not: hence an option, and 0 the default.  Specification: oracle/port.c with port_set_bvh_cull(1). */
     CHUNKY_OPT_BVH_CULL_BEHIND = 8  /* int: 0 (default) / 1 */
 } chunky_option;
 int chunky_render_set_option(chunky_render* r, int option, int32_t value);

@@ -246,3 +246,31 @@ def plus_z_scene() -> scenes.PackedScene:
                             bvh_trigs=np.zeros(1, np.int32), atlas=np.zeros((1, 16, 16, 4), np.uint8),
                             sky=scenes.bake_sky(16), sky_intensity=1.0, sun=scenes.pack_sun(0.6, 1.2, 1.0, False),
                             camera=scenes.look_at_camera((4.5, 4.5, 7.5), (4.5, 4.5, 4.5), 40.0), width=9, height=9)
+
+
+# ---- the scene of tools/cull_probe.py / tests/test_bvh_cull.py: entity boxes ON the block grid ----
+GRID_BOXES = 1500
+
+
+def grid_boxes(seed=5):
+    """tiny_scene's palettes with a world BVH of GRID_BOXES axis-aligned boxes with integer corners (12 triangles each, a third of
+    the boxes two-sided): every face lies in a plane that rays leave from.  Returns (scene, box minima, box maxima)."""
+    import dataclasses
+    base = scenes.tiny_scene(seed=3, size=16, width=16, height=8, entities=0)
+    rng = np.random.default_rng(seed)
+    nmat = len(base.material_palette) // 6
+    lo = rng.integers(2, 60, size=(GRID_BOXES, 3)).astype(np.float64)
+    hi = lo + rng.integers(1, 4, size=(GRID_BOXES, 3))
+    tris = []
+    for b in range(GRID_BOXES):
+        x0, y0, z0 = lo[b]
+        x1, y1, z1 = hi[b]
+        v = np.array([[x0, y0, z0], [x1, y0, z0], [x1, y1, z0], [x0, y1, z0], [x0, y0, z1], [x1, y0, z1], [x1, y1, z1], [x0, y1, z1]])
+        mat = 6 * int(rng.integers(0, nmat))
+        ds = bool(rng.random() < 0.33)
+        for (i, j, k) in ((0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (3, 6, 2), (3, 7, 6), (0, 4, 7), (0, 7, 3), (1, 2, 6), (1, 6, 5)):
+            tris.append(scenes.pack_triangle(v[i], v[j], v[k], (0, 0), (1, 0), (0, 1), mat, ds))
+    t = np.array(tris, np.int64).astype(np.int32).reshape(-1, 20)
+    wn, wtr = scenes.build_bvh(t, 4)
+    sc = dataclasses.replace(base, world_bvh=wn, actor_bvh=scenes.empty_bvh(), bvh_trigs=wtr, name="grid_boxes")
+    return sc, lo.astype(np.float32), hi.astype(np.float32)
