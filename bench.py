@@ -218,15 +218,21 @@ def nearest_ceiling(pm, physical_frac):
     if not pm:
         return None
     lim = pm.get("limits", {})
-    cand = {"valu_issue": lim.get("valu_issue_frac"), "l1_tag_lookups": lim.get("l1_tag_lookups_per_cycle"),
+    l1 = lim.get("l1_tag_lookup_frac")
+    if l1 is None and lim.get("l1_tag_lookups_per_cycle") is not None:  # (an entry collected before round 5: per cycle, against the measured 1.56)
+        l1 = lim["l1_tag_lookups_per_cycle"] * 0.64
+    cand = {"valu_issue": lim.get("valu_issue_frac"), "l1_tag_lookups": l1,
             "scalar_pipe": lim.get("scalar_pipe_frac"), "l2_requests": lim.get("l2_request_frac_of_34.5TBps"), "hbm_physical": physical_frac}
     cand = {k: float(v) for k, v in cand.items() if v is not None}
     if not cand:
         return None
     best = max(cand, key=cand.get)
     return {"resource": best, "frac": round(cand[best], 4), "all": {k: round(v, 4) for k, v in sorted(cand.items(), key=lambda kv: -kv[1])},
-            "note": "used / available per resource over the launch (profiles/pmc_traffic.json); valu_issue counts issue slots, not useful "
-                    "lanes (x valu_lane_util for those); the contract `frac` above is a work-rate convention, this is the hardware view"}
+            "wave_wait_frac": lim.get("wave_wait_frac"), "valu_lane_util": lim.get("valu_lane_util"),
+            "note": "used / available per resource over the launch (profiles/pmc_traffic.json): VALU issue slots (not useful lanes: x valu_lane_util), "
+                    "L1 look-ups against the measured gather rate (1.56 per cycle and CU), scalar pipe = (SALU + branch) per CU-cycle, L2 requests, "
+                    "physical HBM bytes.  No unit saturated + a large wave_wait_frac = latency-bound (paths in flight x latency).  The contract "
+                    "`frac` above is a work-rate convention; this is the hardware view"}
 
 
 def roofline_object(sc, config, info, launch_ms, launches, samples_per_launch, passes_per_launch, seeds, threads, n_rows, kernel_variant,
@@ -673,6 +679,7 @@ def main():
                if group_devices else
                f"image tiles ({'16x16-pixel blocks' if args.tile == 0 else f'runs of {args.tile} px'}) round-robin over {world} GPU(s), scene replicated, "
                f"one RCCL reduce per read-back")
+        box = {"hostname": os.uname().nodename, "gpu": torch.cuda.get_device_name(local_rank), "gpus_visible": torch.cuda.device_count()}
         out = {
             "metric": "Msamples/s, 32x32-chunk scene @1920x1080" if args.config == 2 else f"Msamples/s, BASELINE configs[{args.config}] @{sc.width}x{sc.height}",
             "value": round(value, 3), "unit": "Msamples/s",
@@ -686,7 +693,7 @@ def main():
                        "octree_ints": int(sc.octree.size), "octree_depth": int(sc.octree_depth),
                        "entity_bvh_ints": int(len(sc.world_bvh) + len(sc.actor_bvh)),
                        "parallelism": how, "kernel_variant": args.kernel},
-            "roofline": roof,
+            "roofline": roof, "box": box,
         }
         # the same samples without the read-backs (exchange + copy to the host): what the kernels alone sustain with everything in HBM
         rb_s = (sum(my_reduce_ms) + sum(my_d2h_ms)) * 1e-3

@@ -16,6 +16,7 @@ namespace chunky {
 hipError_t launch_render(int, const SceneView&, const CameraView&, const RenderOpts&, const ShardView&, const PassSeeds&, float*, int*, hipStream_t, KernelChoice*, float*, const int*) { return hipErrorNotSupported; }
 bool pool_kernel_applies(int, const SceneView&, const RenderOpts&, bool) { return false; }
 hipError_t launch_gather(bool, const ShardView&, int, int, float*, float*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_clear_foreign(const ShardView&, int, int, float*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_trace_records(int, const SceneView&, const CameraView&, const RenderOpts&, int, const int*, int, HitRecord*, int*, float*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_preview(int, const SceneView&, const CameraView&, const RenderOpts&, int*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_filter(long long, float, const double*, unsigned*, int, hipStream_t, const float*) { return hipErrorNotSupported; }
