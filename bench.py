@@ -41,9 +41,11 @@ The JSON line also carries:
   image_check  — after the timed region every rank renders 4 passes of the same view, the read-back collective runs once
                  more, and rank 0 compares whole image rows with tests/golden/timed_rows.npz (rendered by the REFERENCE
                  build): the first multi-GPU run says by itself whether the reduced image is the reference's.
-  group_check  — N > 1: rank 0 alone then opens ALL N GPUs behind one context (chunky_group_create, the in-process path a
-                 JVM binds), renders one step, and reports per-member peer-access status, kernel and gather milliseconds
-                 and the same image check; a failure is reported in the line, it does not fail the bench.
+  group_check  — N > 1: a child process of rank 0 (watchdog: 240 s) then opens ALL N GPUs behind one context
+                 (chunky_group_create, the in-process path a JVM binds: RCCL called from C++), renders one step, and reports
+                 per-member peer-access status, the transport and the gather milliseconds of every transport (RCCL send/recv,
+                 RCCL reduce, peer copies), and the same image check; a failure or a hang is reported in the line, it does
+                 not fail the bench.
   per_rank     — N > 1: every rank's kernel milliseconds (HIP events) and the milliseconds of its read-back reduces.
   cpu_baseline — the C restatement of the reference kernel (oracle/port.c, kind "port") timed on this box's host cores
                  (workers pinned one per CPU) on a bounded sample of the same view (rank 0, N = 1).
@@ -368,6 +370,36 @@ def group_leg(devices, sc, seeds, passes, gold, kernel_variant):
         inst.close()
 
 
+def group_leg_in_child(devices, args, timeout_s=240.0):
+    """group_leg in a process of its own, under a watchdog: the first contact of chunky_group_create (peer access, an RCCL
+    communicator over every GPU of the node) with real multi-GPU hardware must not be able to take the bench line with it.  The
+    child is started, never exec'ed in place; if it does not answer in time it is ended by its own PID and the line says so."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--group-leg-child", ",".join(str(d) for d in devices), "--config", str(args.config),
+           "--kernel", str(args.kernel), "--width", str(args.width), "--height", str(args.height), "--chunks", str(args.chunks)]
+    if args.passes > 0:
+        cmd += ["--passes", str(args.passes)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK")}
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    try:
+        so, se = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        try:
+            so, se = proc.communicate(timeout=20)
+        except Exception:
+            so, se = "", ""
+        return {"error": f"no answer within {timeout_s:.0f} s (the child was ended)", "stderr_tail": (se or "")[-600:]}
+    lines = [ln for ln in (so or "").splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        return {"error": f"child exited with {proc.returncode}", "stderr_tail": (se or "")[-600:]}
+    out = json.loads(lines[-1])
+    out["ran_in"] = f"a child process of rank 0 ({time.perf_counter() - t0:.1f} s incl. start-up and scene upload)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -393,7 +425,18 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rigs")
     ap.add_argument("--one-device", action="store_true", help="rig: every rank uses GPU 0 (1-GPU box, with --backend gloo)")
     ap.add_argument("--spawn", action="store_true", help="run even N = 1 as a child rank through the self-spawn path (rig)")
+    ap.add_argument("--group-leg-child", default="", help="internal: run the group_check leg on these devices (d0,d1,...) and print its JSON object")
     args = ap.parse_args()
+
+    if args.group_leg_child:
+        from chunkyclplugin_amd import native
+        devices = [int(d) for d in args.group_leg_child.split(",")]
+        sc, passes, golden_name, _what, _spp = workload(args.config, args)
+        if args.passes > 0:
+            passes = args.passes
+        seeds = native.java_random_ints(max(passes, MERGE_INTERVAL))
+        print(json.dumps(group_leg(devices, sc, seeds, passes, golden_rows(golden_name), args.kernel)), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -679,7 +722,8 @@ def main():
                if group_devices else
                f"image tiles ({'16x16-pixel blocks' if args.tile == 0 else f'runs of {args.tile} px'}) round-robin over {world} GPU(s), scene replicated, "
                f"one RCCL reduce per read-back")
-        box = {"hostname": os.uname().nodename, "gpu": torch.cuda.get_device_name(local_rank), "gpus_visible": torch.cuda.device_count()}
+        box = {"hostname": os.uname().nodename, "gpu": inst.device_name() if not group_devices else torch.cuda.get_device_name(local_rank),
+               "gpus_visible": torch.cuda.device_count()}
         out = {
             "metric": "Msamples/s, 32x32-chunk scene @1920x1080" if args.config == 2 else f"Msamples/s, BASELINE configs[{args.config}] @{sc.width}x{sc.height}",
             "value": round(value, 3), "unit": "Msamples/s",
@@ -747,7 +791,7 @@ def main():
             store = None
         if rank == 0:
             try:
-                out["group_check"] = group_leg(sorted(devices_seen), sc, seeds, passes, gold, args.kernel)
+                out["group_check"] = group_leg_in_child(sorted(devices_seen), args)
             except Exception as e:  # first contact with real multi-GPU hardware: report, do not fail the bench
                 out["group_check"] = {"error": f"{type(e).__name__}: {e}"}
             if store is not None:
