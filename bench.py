@@ -854,6 +854,13 @@ def main():
                 "unavailable: " + ("no JDK (`java` not on PATH)" if not shutil.which("java") else "a JDK but no chunky-core jar") + " on this box"
                 if not (shutil.which("java") and jars) else f"found {jars[0]} (not driven by this bench)")
         print(json.dumps(out), flush=True)
+        # the line is the LAST thing on stdout: whatever a native library prints while it shuts down (RCCL announces itself on
+        # stdout) goes to stderr from here on
+        try:
+            sys.stdout.flush()
+            os.dup2(2, 1)
+        except Exception:
+            pass
 
     try:  # the line is out: a hiccup while tearing down must not turn a measured run into a failed one
         r.close()

@@ -145,8 +145,15 @@ int main(int argc, char** argv) {
         return 1;
     }
     fclose(f);
-    printf("{\"device\": \"%s\", \"members\": %d, \"size\": [%d, %d], \"spp\": %d, \"seconds\": %.4f, \"Msamples_per_s\": %.2f, \"launches\": %d, \"kernel_ms\": %.3f}\n",
-           name, chunky_group_size(ctx), width, height, spp, dt, (double)width * height * spp / dt / 1e6, launches, kernel_ms);
+    // what carried the read-back exchange of a group (RCCL called from inside the library, or its peer-copy fallback, and why)
+    int transport = 0;
+    char detail[256] = "";
+    TRY(chunky_group_transport(ctx, &transport, detail, sizeof detail));
+    for (char* p = detail; *p; p++)
+        if (*p == '"' || *p == '\\') *p = '\'';
+    printf("{\"device\": \"%s\", \"members\": %d, \"size\": [%d, %d], \"spp\": %d, \"seconds\": %.4f, \"Msamples_per_s\": %.2f, \"launches\": %d, \"kernel_ms\": %.3f, "
+           "\"transport\": %d, \"transport_detail\": \"%s\"}\n",
+           name, chunky_group_size(ctx), width, height, spp, dt, (double)width * height * spp / dt / 1e6, launches, kernel_ms, transport, detail);
     TRY(chunky_render_destroy(r));
     TRY(chunky_scene_destroy(scene));
     TRY(chunky_shutdown(ctx));

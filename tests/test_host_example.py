@@ -67,6 +67,7 @@ def test_host_example_runs_the_reference_pass_loop(host_example, tmp_path, port,
     assert proc.returncode == 0, proc.stderr
     line = json.loads(proc.stdout.strip().splitlines()[-1])
     assert line["spp"] == target and line["members"] == 1 and line["size"] == [64, 48]
+    assert line["transport"] == native.TRANSPORT_PEER_COPY and "single device" in line["transport_detail"]   # nothing to exchange
     got = np.fromfile(out, np.float64)
     np.testing.assert_array_equal(got.view(np.uint64), oracle_loop(port, sc, target, interval).view(np.uint64))
 
@@ -80,5 +81,7 @@ def test_host_example_on_a_group(host_example, tmp_path, port):
     assert proc.returncode == 0, proc.stderr
     line = json.loads(proc.stdout.strip().splitlines()[-1])
     assert line["members"] == 3
+    # members sharing a device cannot be RCCL ranks: the C host sees the fallback and its reason through chunky_group_transport
+    assert line["transport"] == native.TRANSPORT_PEER_COPY and "share device 0" in line["transport_detail"], line
     got = np.fromfile(out, np.float64)
     np.testing.assert_array_equal(got.view(np.uint64), oracle_loop(port, sc, target, interval).view(np.uint64))

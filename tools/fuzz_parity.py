@@ -23,6 +23,13 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     inst = RendererInstance.get(0)
     groups = {n: RendererInstance.group([0] * n) for n in (2, 3)}   # several members behind one context (chunky_group_create), sharing the GPU
+    # ... and a one-member group, which owns a real RCCL communicator: with CHUNKY_GROUP_SELF_EXCHANGE its own blocks go through the
+    # read-back exchange (packed, sent to itself, received, scattered — or reduced in place), by a transport drawn per configuration
+    os.environ["CHUNKY_GROUP_SELF_EXCHANGE"] = "1"
+    groups[1] = RendererInstance.group([0])
+    rccl = groups[1].transport()["backend"] == "rccl"
+    print("fuzz: one-member group:", groups[1].transport(), flush=True)
+    transports_used = {}
     port = binding.port()
     bad = 0
     for it in range(n_iter):
@@ -60,7 +67,11 @@ def main():
         # a fifth of the pool-kernel cases run on a multi-member group: its members split the share again, the read-back gathers
         # (any kernel variant: members hold block shares, which the fallback kernels render from a pixel list; a large draw depth
         # sends the pool kernel's cases to the fallback too)
-        on_group = int(rng.choice([2, 3])) if rng.random() < 0.2 else 0
+        on_group = int(rng.choice([1, 1, 2, 3])) if rng.random() < 0.3 else 0
+        if on_group == 1:
+            t = int(rng.choice([native.TRANSPORT_RCCL_SENDRECV, native.TRANSPORT_RCCL_REDUCE, native.TRANSPORT_PEER_COPY])) if rccl else native.TRANSPORT_PEER_COPY
+            groups[1].set_transport(t)
+            transports_used[t] = transports_used.get(t, 0) + 1
         if not ext and rng.random() < 0.05:
             draw = 70000
         # entity-BVH placement (addresses only) and the behind-the-ray cull (an extension with its own oracle mode)
@@ -102,6 +113,7 @@ def main():
         loader.close()
         if (it + 1) % 2000 == 0:
             print(f"fuzz: {it + 1} of {n_iter} configurations from seed {seed0} so far, {bad} differed", flush=True)
+    print(f"fuzz: one-member group ended on {groups[1].transport()['name']}; configurations per transport {transports_used}")
     print(f"fuzz: {n_iter} configurations from seed {seed0}, {bad} differed")
     sys.exit(1 if bad else 0)
 
