@@ -98,9 +98,6 @@ struct DevBuf {
 struct chunky_scene {
     chunky_ctx* ctx = nullptr;
     DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, quad_aux;
-    DevBuf narrow;                                     // experiment 5.4: NarrowTree top (4-byte entries) followed by its nodes
-    size_t narrow_top_entries = 0;
-    int narrow_bytes = 0;
     DevBuf mat8, aabb_rec, quad_rec;                   // 16-byte-aligned re-layouts of the palettes (rt_device.hpp)
     DevBuf bvh_rec;                                    // both entity BVHs as 64-byte inner nodes, then their triangles as 80-byte records
     size_t tri_off = 0;                                // byte offset of the first triangle record in bvh_rec
@@ -1168,17 +1165,6 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
         HIP_TRY(hipStreamSynchronize(s->ctx->stream));  // queued passes may still read the old copy
         HIP_TRY(s->wide.upload(s->wide_meta.data.data(), s->wide_meta.data.size() * 4, s->ctx->stream));
         s->wide_dirty = false;
-        s->narrow.release();
-        s->narrow_bytes = 0;
-        NarrowTree nt;
-        if (getenv("CHUNKY_NARROW_TREE") && build_narrow_tree(s->wide_meta, &nt)) {  // experiment 5.4
-            std::vector<uint8_t> both(nt.top.size() * 4 + nt.nodes.size());
-            memcpy(both.data(), nt.top.data(), nt.top.size() * 4);
-            memcpy(both.data() + nt.top.size() * 4, nt.nodes.data(), nt.nodes.size());
-            HIP_TRY(s->narrow.upload(both.data(), both.size(), s->ctx->stream));
-            s->narrow_top_entries = nt.top.size();
-            s->narrow_bytes = nt.entry_bytes;
-        }
     }
     if (s->derived_dirty)
         if (int rc = rebuild_derived(s)) return rc;
@@ -1219,9 +1205,6 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     v->quad_rec = (const int4*)s->quad_rec.p;
     v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;
     v->wide_nlev = s->wide_meta.nlev;
-    v->narrow_top = s->narrow_bytes ? (const uint32_t*)s->narrow.p : nullptr;
-    v->narrow_nodes = s->narrow_bytes ? (const uint8_t*)s->narrow.p + s->narrow_top_entries * 4 : nullptr;
-    v->narrow_bytes = s->narrow_bytes;
     for (int i = 0; i < 6; i++) {
         v->wide_shift[i] = s->wide_meta.shift[i];
         v->wide_bits[i] = s->wide_meta.bits[i];
@@ -2044,44 +2027,6 @@ extern "C" int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int d
         level_out[i] = (e >> 27) & 15;
         uint32_t code = (uint32_t)e & kWideAny;
         data_out[i] = code == kWideAny ? 0x7FFFFFFE : (int32_t)(code & kWidePtrMask);
-    }
-    return CHUNKY_OK;
-}
-
-// Host-side check of the narrow last level (experiment 5.4): the lookup through NarrowTree, decoded as the kernels decode it.
-extern "C" int chunky_narrowtree_lookup(const int32_t* tree, int64_t n_ints, int depth, const int32_t* blocks, int64_t n_block_ints,
-                                        const int32_t* xyz, int n, int32_t* data_out, int32_t* level_out, int32_t* kind_out,
-                                        int32_t* entry_bytes) {
-    if (int rc = check_ints(tree, n_ints, "narrowtree_lookup")) return rc;
-    if (n_ints < 1 || n < 0 || !entry_bytes || (n > 0 && (!xyz || !data_out || !level_out || !kind_out))) return fail(CHUNKY_E_INVALID, "narrowtree_lookup: bad arguments");
-    int bits[kWideMaxLevels];
-    const int nlev = default_wide_levels(depth, bits);
-    WideTree wt;
-    const char* why = "";
-    if (!build_wide_tree(tree, n_ints, depth, bits, nlev, &wt, &why)) return fail(CHUNKY_E_INVALID, "wide tree: %s", why);
-    annotate_wide_tree(&wt, blocks, n_block_ints);
-    NarrowTree nt;
-    *entry_bytes = 0;
-    if (!build_narrow_tree(wt, &nt)) return CHUNKY_OK;  // not narrowable: the caller sees 0 entry bytes
-    *entry_bytes = nt.entry_bytes;
-    const int tb = wt.bits[0];
-    for (int i = 0; i < n; i++) {
-        const int x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        if (((x | y | z) >> depth) != 0) return fail(CHUNKY_E_INVALID, "narrowtree_lookup: cell outside the world");
-        int32_t e = (int32_t)nt.top[(size_t)((((x >> 3) << tb) | (y >> 3)) << tb | (z >> 3))];
-        if (e >= 0) {
-            const size_t at = (size_t)e + (size_t)(((x & 7) << 6) | ((y & 7) << 3) | (z & 7));
-            if (nt.entry_bytes == 2) {
-                const uint32_t h = (uint32_t)nt.nodes[2 * at] | ((uint32_t)nt.nodes[2 * at + 1] << 8);
-                e = (int32_t)(((h & 0xF000u) << 13) | (h & 0xFFFu));
-            } else {
-                const uint32_t h = nt.nodes[at];
-                e = (int32_t)(((h & 0xF0u) << 21) | (h & 0xFu));
-            }
-        }
-        level_out[i] = (e >> 27) & 15;
-        kind_out[i] = (int32_t)(((uint32_t)e >> 25) & 3u);
-        data_out[i] = (int32_t)(((uint32_t)e & 0xFFFFFFu) << 1);
     }
     return CHUNKY_OK;
 }

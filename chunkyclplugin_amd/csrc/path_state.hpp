@@ -39,25 +39,6 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
         data = -data;
         // (a block pointer beyond the palette — hostile data; the reference's read there is undefined — never intersects)
         kind = (data == 0 || data == kAnyType || (unsigned)data + 1u >= (unsigned)S.n_block_ints) ? 2 : 1;
-    } else if (TREE == 20 || TREE == 24) {
-        // EXPERIMENT 5.4: dense top (4-byte entries) over one level of 8^3 nodes of 2-byte (20) / 1-byte (24) leaves
-        const int tb = S.wide_bits[0];
-        unsigned idx = (((((unsigned)bx >> 3) << tb) | ((unsigned)by >> 3)) << tb) | ((unsigned)bz >> 3);
-        idx = inside ? idx : 0u;
-        int e = *(const int*)((const char*)S.narrow_top + (idx << 2));
-        if (e >= 0) {
-            const unsigned at = (unsigned)e + ((((unsigned)bx & 7u) << 6) | (((unsigned)by & 7u) << 3) | ((unsigned)bz & 7u));
-            if (TREE == 20) {
-                const unsigned h = *(const unsigned short*)((const char*)S.narrow_nodes + (at << 1));
-                e = (int)(((h & 0xF000u) << 13) | (h & 0xFFFu));
-            } else {
-                const unsigned h = *(const unsigned char*)((const char*)S.narrow_nodes + at);
-                e = (int)(((h & 0xF0u) << 21) | (h & 0xFu));
-            }
-        }
-        level = (e >> 27) & 15;
-        kind = (int)(((unsigned)e >> 25) & 3u);
-        data = (int)(((unsigned)e & 0xFFFFFFu) << 1);
     } else {
         const uint32_t* __restrict__ tree = S.wide;
         int e = 0;
@@ -649,7 +630,6 @@ inline bool use_wide(int variant, const SceneView& S) { return S.wide != nullptr
 // the form of leaf_lookup for a scene: 0 reference layout, 16 + n dense top over n levels of 8x8x8 nodes, -1 any other wide split
 inline int tree_form(int variant, const SceneView& S) {
     if (!use_wide(variant, S)) return 0;
-    if ((variant & 1024) && S.narrow_top && S.wide_nlev == 2) return S.narrow_bytes == 1 ? 24 : 20;  // experiment 5.4
     int tree = S.wide_nlev <= 4 ? 16 + S.wide_nlev - 1 : -1;
     for (int i = 1; i < S.wide_nlev; i++)
         if (S.wide_bits[i] != 3) tree = -1;

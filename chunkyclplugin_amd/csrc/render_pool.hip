@@ -764,8 +764,6 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
             case 17: k = render_pool<17, kPoolPark, false>; break;
             case 18: k = render_pool<18, kPoolPark, false>; break;
             case 19: k = render_pool<19, kPoolPark, false>; break;
-            case 20: k = render_pool<20, kPoolPark, false>; break;
-            case 24: k = render_pool<24, kPoolPark, false>; break;
             default: tree = -1; k = render_pool<-1, kPoolPark, false>; break;
         }
     }

@@ -70,10 +70,6 @@ struct SceneView {
     const uint32_t* __restrict__ wide;
     int wide_nlev;
     int wide_shift[6], wide_bits[6];
-    // EXPERIMENT 5.4: the same tree with its last level in 1- or 2-byte entries (widetree.hpp NarrowTree); null when it cannot be
-    const uint32_t* __restrict__ narrow_top;
-    const uint8_t* __restrict__ narrow_nodes;
-    int narrow_bytes;
     // per block (index = block pointer / 2) 8 ints: {modelType, modelPointer, material words 0..4 of a
     // full cube (K/material.h:31-40), 0} — the block-palette and material-palette reads of
     // K/block.h:36-49 as ONE 32-byte load; built at upload, null when a palette is missing

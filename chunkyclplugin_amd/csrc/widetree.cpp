@@ -130,54 +130,4 @@ void annotate_wide_tree(WideTree* t, const int32_t* blocks, int64_t n) {
     }
 }
 
-bool build_narrow_tree(const WideTree& t, NarrowTree* out) {
-    out->entry_bytes = 0;
-    out->top.clear();
-    out->nodes.clear();
-    if (t.nlev != 2 || t.bits[1] != 3) return false;
-    const size_t top_n = (size_t)1 << (3 * t.bits[0]);
-    if (t.data.size() < top_n || (t.data.size() - top_n) % 512 != 0) return false;
-    // (a leaf: flag, level << 27, kind << 25 — set by annotate_wide_tree — and the block pointer in 25 bits; ANY_TYPE = all ones)
-    auto is_any = [](uint32_t e) { return (e & kWideAny) == kWideAny; };
-    uint32_t most = 0;  // the largest pointer / 2 of the last level decides the entry size
-    for (size_t i = 0; i < t.data.size(); i++) {
-        const uint32_t e = t.data[i];
-        if (!(e & kWideLeaf)) {
-            if (i >= top_n) return false;  // (a branch below the last level cannot exist: build_wide_tree refuses it)
-            continue;
-        }
-        if (is_any(e)) continue;
-        const uint32_t ptr = e & kWidePtrMask;
-        if ((ptr & 1u) || (i >= top_n && ((e >> 27) & 15u) > 3u)) return false;
-        if (i >= top_n && (ptr >> 1) > most) most = ptr >> 1;
-    }
-    int bytes = most < 0xFu ? 1 : (most < 0xFFFu ? 2 : 0);
-    if (const char* e = getenv("CHUNKY_NARROW_TREE"))  // (tuning runs: "2" keeps 2-byte entries where 1-byte ones would do)
-        if (bytes == 1 && atoi(e) == 2) bytes = 2;
-    if (!bytes) return false;
-    out->top.resize(top_n);
-    for (size_t i = 0; i < top_n; i++) {
-        const uint32_t e = t.data[i];
-        if (e & kWideLeaf)
-            out->top[i] = (e & 0xFE000000u) | (is_any(e) ? 0xFFFFFFu : ((e & kWidePtrMask) >> 1));
-        else
-            out->top[i] = e - (uint32_t)top_n;  // entries into `nodes`
-    }
-    const size_t n_low = t.data.size() - top_n;
-    out->nodes.resize(n_low * (size_t)bytes);
-    for (size_t i = 0; i < n_low; i++) {
-        const uint32_t e = t.data[top_n + i];
-        const uint32_t level = (e >> 27) & 3u, kind = (e >> kWideKindShift) & 3u, half = (e & kWidePtrMask) >> 1;
-        if (bytes == 1) {
-            out->nodes[i] = (uint8_t)(level << 6 | kind << 4 | (is_any(e) ? 0xFu : half));
-        } else {
-            const uint16_t h = (uint16_t)(level << 14 | kind << 12 | (is_any(e) ? 0xFFFu : half));
-            out->nodes[2 * i] = (uint8_t)(h & 0xFF);
-            out->nodes[2 * i + 1] = (uint8_t)(h >> 8);
-        }
-    }
-    out->entry_bytes = bytes;
-    return true;
-}
-
 }  // namespace chunky

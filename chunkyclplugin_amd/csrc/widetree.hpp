@@ -43,17 +43,6 @@ bool build_wide_tree(const int32_t* oct, int64_t n_ints, int depth, const int* l
 // Sets the kind bits of every leaf from the block palette (2 ints per block: modelType, pointer).
 void annotate_wide_tree(WideTree* t, const int32_t* block_palette, int64_t n_ints);
 
-// EXPERIMENT 5.4 — a dense top over ONE level of 8^3 nodes whose entries (all of them leaves of level 0..2) are stored in
-// 1 or 2 bytes instead of 4: [level:2][kind:2][block pointer / 2 : 4 or 12] (all ones = ANY_TYPE).  The top keeps 4-byte entries:
-// a leaf as 0x80000000 | level << 27 | kind << 25 | pointer / 2, a child as the index of its node's first entry in `nodes`.
-// Same (data, level, kind) for every cell as the wide tree it is made from.
-struct NarrowTree {
-    std::vector<uint32_t> top;
-    std::vector<uint8_t> nodes;
-    int entry_bytes = 0;  // 1 or 2; 0 = the tree cannot be narrowed (more than two levels, odd or large block pointers)
-};
-bool build_narrow_tree(const WideTree& t, NarrowTree* out);
-
 // Default split: ceil(depth/3) levels of 3 bits each (top level padded), see widetree.cpp.
 int default_wide_levels(int depth, int* level_bits);
 

@@ -168,7 +168,6 @@ def lib() -> C.CDLL:
             "chunky_filter_gamma_thresholds": [vp],
             "chunky_filter_frame_device": [vp, i64, f32, vp, vp, C.c_int, C.c_int, C.POINTER(f32)],
             "chunky_widetree_lookup": [vp, i64, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.POINTER(i64)],
-            "chunky_narrowtree_lookup": [vp, i64, C.c_int, vp, i64, vp, C.c_int, vp, vp, vp, C.POINTER(i32)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)

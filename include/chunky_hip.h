@@ -330,12 +330,6 @@ int chunky_filter_frame_device(chunky_ctx* ctx, int64_t n_pixels, float exposure
  * uses the default split.  *n_entries receives the size of the re-laid-out array. */
 int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int depth, const int32_t* level_bits, int n_levels,
                            const int32_t* xyz /* 3n */, int n, int32_t* data_out, int32_t* level_out, int64_t* n_entries);
-/* Host-side check of the narrow last level of the octree re-layout (a dense top over one level of 8^3 nodes whose leaves are
- * stored in 1 or 2 bytes; csrc/widetree.hpp NarrowTree): (block pointer, leaf level, kind) of each cell as the kernels decode
- * them, kinds from the block palette `blocks`; *entry_bytes = 0 when the tree cannot be narrowed (nothing else is written). */
-int chunky_narrowtree_lookup(const int32_t* tree, int64_t n_ints, int depth, const int32_t* blocks, int64_t n_block_ints,
-                             const int32_t* xyz, int n, int32_t* data_out, int32_t* level_out, int32_t* kind_out,
-                             int32_t* entry_bytes);
 
 /* ---- self test: evaluate the rt_math.h contract on the device (bit-compared with the host by tests) */
 int chunky_selftest_math(chunky_ctx* ctx, int which, int n, const float* a, const float* b, float* out);
