@@ -202,7 +202,8 @@ static int n_local_slots(int width, int height, const ShardView& t) {
 // ------------------------------------------------------------------------------------ device
 extern "C" const char* chunky_last_error(void) { return tls_error.c_str(); }
 // 0.4: chunky_run_callbacks carries its size (an ABI change), chunky_group_peer_status, CHUNKY_OPT_BVH_CULL_BEHIND
-extern "C" const char* chunky_version(void) { return "chunky-hip 0.4 gfx950"; }
+// 0.5: chunky_group_transport / chunky_group_set_transport (the group's read-back exchange through RCCL, bound at run time)
+extern "C" const char* chunky_version(void) { return "chunky-hip 0.5 gfx950"; }
 
 extern "C" int chunky_device_count(void) {
     int n = 0;
