@@ -1629,6 +1629,15 @@ static int group_gather_peer(chunky_render* r) {
     return gather_scatter(r, 1);
 }
 
+// (inside an open ncclGroupStart: a failing HIP call closes the group before it returns)
+#define HIP_TRY_IN_GROUP(expr)                                                                   \
+    do {                                                                                         \
+        const hipError_t h_ = (expr);                                                            \
+        if (h_ != hipSuccess) {                                                                  \
+            if (in_group) (void)api.GroupEnd();                                                  \
+            return fail(CHUNKY_E_HIP, "%s: %s", #expr, hipGetErrorString(h_));                  \
+        }                                                                                        \
+    } while (0)
 #define RCCL_TRY(expr)                                                                           \
     do {                                                                                         \
         const ncclResult_t e_ = (expr);                                                          \
@@ -1660,9 +1669,9 @@ static int group_gather_sendrecv(chunky_render* r) {
         chunky_render* pi = r->parts[i];
         const size_t count = (size_t)pi->shard.n_local * 3;
         if (count == 0) continue;
-        HIP_TRY(hipSetDevice(pi->ctx->device));
+        HIP_TRY_IN_GROUP(hipSetDevice(pi->ctx->device));
         RCCL_TRY(api.Send(r->gather_send[i].p, count, ncclFloat, 0, g->comms[i], pi->ctx->stream));
-        HIP_TRY(hipSetDevice(p0->ctx->device));
+        HIP_TRY_IN_GROUP(hipSetDevice(p0->ctx->device));
         RCCL_TRY(api.Recv(r->gather_recv[i].p, count, ncclFloat, (int)i, g->comms[0], p0->ctx->stream));
     }
     in_group = false;
@@ -1698,7 +1707,7 @@ static int group_gather_reduce(chunky_render* r) {
     in_group = true;
     for (size_t i = 0; i < n; i++) {
         chunky_render* pi = r->parts[i];
-        HIP_TRY(hipSetDevice(pi->ctx->device));
+        HIP_TRY_IN_GROUP(hipSetDevice(pi->ctx->device));
         RCCL_TRY(api.Reduce(pi->fb, pi->fb, count, ncclFloat, ncclSum, 0, g->comms[i], pi->ctx->stream));
     }
     in_group = false;
@@ -1716,6 +1725,7 @@ static int group_gather_reduce(chunky_render* r) {
     return CHUNKY_OK;
 }
 #undef RCCL_TRY
+#undef HIP_TRY_IN_GROUP
 
 static int group_gather(chunky_render* r) {
     chunky_ctx* g = r->ctx;
