@@ -47,10 +47,10 @@ The JSON line also carries:
                  RCCL reduce, peer copies), and the same image check; a failure or a hang is reported in the line, it does
                  not fail the bench.
   per_rank     — N > 1: every rank's kernel milliseconds (HIP events) and the milliseconds of its read-back reduces.
-  cpu_baseline — the C restatement of the reference kernel (oracle/port.c, kind "port") timed on this box's host cores
-                 (workers pinned one per CPU) on a bounded sample of the same view (rank 0, N = 1); where oracle/_ref travelled
-                 with the tree, `reference_build` beside it: the reference's own rayTracer.cl compiled for the host, on a band
-                 of rows of the same view (slower than the restatement: its builtins are calls through the shim).
+  cpu_baseline — where oracle/_ref travelled with the tree: the reference kernel itself (rayTracer.cl compiled for x86-64 by
+                 clang in the build container: kind "reference") timed on this box's host cores on a bounded sample of the same
+                 view (rank 0, N = 1), with the C restatement's rate (oracle/port.c, workers pinned) on the same sample beside it;
+                 else the restatement alone (kind "port").
 """
 import argparse
 import json
@@ -846,33 +846,31 @@ def main():
                                    "scaling": "profiles/r04_cpu_sweep.jsonl (1 ... 256 threads on this box type: 0.86 of linear at 8 threads, "
                                               "flat from the quota on, slower beyond it)"}
             # where the reference build itself travelled with the tree (oracle/_ref: the reference's rayTracer.cl compiled for the
-            # host by clang in the build container, never rebuilt here): a band of whole rows of the same view through it, about four
-            # seconds' worth, reported BESIDE the restatement — it calls the 27 OpenCL builtins through the shim (no inlining) and
-            # starts its threads per pass, so it is the slower of the two and the restatement stays the baseline
+            # host by clang in the build container, never rebuilt here): the SAME sample through it — the baseline is then the
+            # reference kernel (kind "reference"), and the restatement's rate on that sample stays beside it
             try:
+                from oracle import binding
                 refk = binding.ref(build=False)
             except Exception:
                 refk = None
             if refk is not None:
                 h = binding.SceneHandle(sc)
                 res = np.zeros(3 * n_pix, np.float32)
-                mid = (sc.height // 2) * sc.width
-                t_r = time.perf_counter()
-                refk.render_passes(h, seeds[:1], res=res, gid_range=(mid, mid + 8 * sc.width), threads=threads)   # calibration: 8 rows x 1 pass
-                rate_r = 8 * sc.width / max(time.perf_counter() - t_r, 1e-6)
-                band = int(max(8, min(sc.height, rate_r * 4.0 // sc.width)))
-                p_r = int(max(1, min(16, rate_r * 4.0 // (band * sc.width))))
+                band = len(leg_rows)            # whole rows: all of them when the budget bought whole passes, else a band around the centre
                 lo = ((sc.height - band) // 2) * sc.width
                 t_r = time.perf_counter()
-                refk.render_passes(h, seeds[:p_r], res=res, gid_range=(lo, lo + band * sc.width), threads=threads)
+                refk.render_passes(h, seeds[:p_cpu], res=res, gid_range=(lo, lo + band * sc.width), threads=threads)
                 dt_r = time.perf_counter() - t_r
-                n_r = band * sc.width * p_r
-                out["cpu_baseline"]["reference_build"] = {
-                    "value": round(n_r / dt_r / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "reference",
-                    "sample": f"{n_r} samples = {band} whole rows around the centre of the same view, {p_r} pass(es), {dt_r:.1f} s of oracle/_ref "
-                              f"(rayTracer.cl compiled for x86-64 by clang, oracle/Makefile) on {threads} host threads",
-                    "note": "the reference kernel itself on the host: slower than the restatement (builtins called through the shim, threads "
-                            "started per pass); the same bits (tests/test_timed_goldens.py)"}
+                n_r = band * sc.width * p_cpu
+                port_leg = out["cpu_baseline"]
+                out["cpu_baseline"] = {
+                    "value": round(n_r / dt_r / 1e6, 4), "unit": "Msamples/s", "cores": threads, "per_thread": round(n_r / dt_r / 1e6 / threads, 5),
+                    "kind": "reference", "pinned": False, "cores_are": threads_how,
+                    "sample": f"{n_r} samples = {band} whole rows of the same {sc.width}x{sc.height} view, {p_cpu} pass(es), {dt_r:.1f} s of oracle/_ref — the "
+                              f"reference's own rayTracer.cl compiled for x86-64 by clang (oracle/Makefile; its OpenCL builtins from rt_math.h) — on "
+                              f"{threads} host threads",
+                    "restatement": {"value": port_leg["value"], "kind": "port", "pinned": True, "sample": port_leg["sample"]},
+                    "scaling": port_leg["scaling"]}
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
             # Chunky's own Java PathTracingRenderer (se.llbit:chunky-core) is timed only where a JDK and a
             # Chunky jar exist on the box; say which it is instead of leaving the question open
