@@ -80,3 +80,26 @@ def test_hip_matches_the_reference_at_timed_sizes(gpu_instance, views, name):
     assert same.all(), f"{name}: {int((~same).sum())} of {len(gids)} pixels differ from the reference build's rows (first gid {int(gids[np.argmin(same)])})"
     r.close()
     loader.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,passes", [("outdoor", 8), ("city", 4), ("city_entities", 2), ("indoor", 4), ("entities", 2), ("entities4k", 1)])
+def test_hip_matches_the_live_reference_build_on_the_whole_image(gpu_instance, ref, views, name, passes):
+    """Where the reference build travelled to the GPU box (oracle/_ref; skipped elsewhere): the WHOLE image of a timed view (1920x1080; 3840x2160 for entities4k) — every pixel, `passes` passes of a java.util.Random stream the committed fixture does not hold — rendered by the reference
+    kernel on the host's CPUs and by the HIP kernels, bit for bit (2 073 600 pixels, 16.6 M samples for the headline view)."""
+    from chunkyclplugin_amd import native
+    from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
+    sc = views(name)
+    seeds = native.java_random_ints(passes, seed=987654321)
+    want = ref.render_passes(binding.SceneHandle(sc), seeds, threads=THREADS)
+    loader = HipSceneLoader(gpu_instance)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, sc.width, sc.height)
+    r.set_camera(sc.projector_type, sc.camera)
+    r.render_passes(seeds)
+    info = r.kernel_info()
+    assert info["tree"] == 17 and info["pool"] > 0, info
+    same = (bits(r.read()) == bits(want)).reshape(-1, 3).all(axis=1)
+    assert same.all(), f"{name}: {int((~same).sum())} of {same.size} pixels differ from the live reference build (first gid {int(np.argmin(same))})"
+    r.close()
+    loader.close()
