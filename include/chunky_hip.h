@@ -85,7 +85,9 @@ int chunky_group_peer_status(chunky_ctx* ctx, int* out, int n);
  * use and a human-readable detail (library file and version, or the reason for the fallback); chunky_group_set_transport
  * picks one (CHUNKY_E_STATE when it needs a communicator that does not exist).  The environment variable
  * CHUNKY_GROUP_TRANSPORT = peer | rccl | rccl-reduce sets the initial choice.  On a chunky_init context: PEER_COPY, nothing
- * to exchange. */
+ * to exchange.  (Two more variables exist for the test rigs that exercise this on ONE GPU, tests/test_gpu_rccl_transport.py:
+ * CHUNKY_GROUP_SELF_EXCHANGE=1 sends member 0's own blocks through the exchange too, CHUNKY_RCCL_TRY_SHARED=1 hands a device
+ * list with duplicates to ncclCommInitAll instead of skipping it.  Neither changes a result.) */
 #define CHUNKY_TRANSPORT_PEER_COPY 0
 #define CHUNKY_TRANSPORT_RCCL_SENDRECV 1
 #define CHUNKY_TRANSPORT_RCCL_REDUCE 2
