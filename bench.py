@@ -73,7 +73,7 @@ def workload(config: int, args):
     if config == 1:
         from chunkyclplugin_amd import octree2
         sc = octree2.cached_benchmark_scene(1920, 1080)
-        return sc, 64, "city", "BASELINE configs[1]: the reference's benchmark/OpenCL_test city (flat-colour cubes), saved camera", 256
+        return sc, 64, "city", "BASELINE configs[1]: the reference's benchmark/OpenCL_test city (procedural asset pack: block models by name and properties, hashed 16x16 textures), saved camera", 256
     if config == 3:
         sc = scenes.indoor_room(size=64, width=1920, img_height=1080)
         return sc, 256, "indoor", "BASELINE configs[3]: indoor emitter room (64^3), sun flag 0, the reference's light transport", 1024

@@ -10,9 +10,12 @@ Appendix D): gzip, big-endian `DataOutputStream`:
                    (x<<2 | y<<1 | z) order, otherwise leaf = palette index, 0x7FFFFFFE = ANY_TYPE)
     water octree:  same (skipped) | biome textures (skipped)
 
-Block models and textures come from Chunky + Minecraft assets, which are not available, so the
-materials are procedural: every visible block becomes a full cube (model type 1) whose material is a
-flat colour derived from crc32(block name), or a hashed 16x16 texture.
+Block models and textures come from Chunky + Minecraft assets, which are not available, so they are
+procedural (`asset_pack`): a palette entry gets the model class its NAME and PROPERTIES say it has — slab
+(bottom / top / double), stairs (half, facing), fence / wall / bars / pane (post + connected arms), carpet /
+rail / plate / trapdoor, door / gate / ladder, crossed-quad plants, small boxes for torches and the like,
+a full cube otherwise — and each block name one 16 x 16 texture hashed from the name (BASELINE.md section 4,
+config 1/2: "16x16 hashed textures"); leaves, plants, bars and panes have cut-out texels.
 """
 from __future__ import annotations
 
@@ -176,6 +179,130 @@ def _block_color(name: str) -> int:
 
 INVISIBLE = {"minecraft:air", "minecraft:cave_air", "minecraft:void_air", "minecraft:barrier", "minecraft:structure_void"}
 
+# ---------------------------------------------------------------------------------------- procedural asset pack
+# Chunky packs every palette entry through its block model and its textures (AbstractSceneLoader.java:101-127, PackedBlock /
+# PackedAabb / PackedQuad); neither chunky-core's models nor Minecraft's textures exist in this image.  What does exist is the
+# palette itself: 3 091 entries with their NAMES and PROPERTIES (slab type, stair half / facing, fence connections ...).  The
+# pack below gives each entry the model class its name and properties say it has — with Minecraft's well-known block geometry
+# for the common classes — and each block NAME one 16 x 16 texture hashed from the name (leaves and plants with cut-out texels).
+# It is a stand-in with the right KIND of geometry and the right mix of model blocks, not Chunky's own output.
+_PLANTS = ("grass", "tall_grass", "fern", "large_fern", "dead_bush", "dandelion", "poppy", "blue_orchid", "allium", "azure_bluet",
+           "oxeye_daisy", "cornflower", "lily_of_the_valley", "wither_rose", "sunflower", "lilac", "rose_bush", "peony", "sugar_cane",
+           "wheat", "carrots", "potatoes", "beetroots", "nether_wart", "sweet_berry_bush", "cobweb", "brown_mushroom", "red_mushroom",
+           "seagrass", "tall_seagrass", "kelp", "kelp_plant", "bamboo", "crimson_roots", "warped_roots", "nether_sprouts",
+           "crimson_fungus", "warped_fungus", "twisting_vines", "weeping_vines", "twisting_vines_plant", "weeping_vines_plant")
+_FLAT = ("rail", "powered_rail", "detector_rail", "activator_rail", "lily_pad", "redstone_wire", "repeater", "comparator", "snow")
+
+
+def _model_class(key: str, props: dict):
+    """(class, parameters) of a palette entry: cube | slab | stairs | thin | post | door | plant | small."""
+    if key.endswith("_slab"):
+        return ("slab", props.get("type", "bottom"))
+    if key.endswith("_stairs"):
+        return ("stairs", props.get("half", "bottom"), props.get("facing", "north"))
+    if key.endswith("_carpet") or key.endswith("_pressure_plate") or key in _FLAT:
+        return ("thin", 0.0625, "bottom")
+    if key.endswith("_trapdoor"):
+        if props.get("open", "false") == "true":
+            return ("door", props.get("facing", "north"), 0.1875)
+        return ("thin", 0.1875, props.get("half", "bottom"))
+    if key.endswith("_door") or key.endswith("_fence_gate") or key == "ladder" or key.endswith("_wall_sign") or key == "vine":
+        return ("door", props.get("facing", "north"), 0.1875 if key.endswith("_door") else 0.125)
+    if key.endswith("_fence") or key.endswith("_wall") or key in ("iron_bars", "chain", "end_rod", "lightning_rod") or key.endswith("glass_pane"):
+        half = 0.25 if key.endswith("_wall") else (0.125 if key.endswith("_fence") else 0.0625)
+        sides = tuple(d for d in ("north", "east", "south", "west") if props.get(d, "false") not in ("false", "none"))
+        return ("post", half, sides, key.endswith("_fence"))
+    if key in _PLANTS or key.endswith("_sapling") or key.endswith("_tulip") or key.endswith("_coral") or key.endswith("_coral_fan"):
+        return ("plant",)
+    if key.endswith("torch") or key.endswith("lantern") or key.endswith("_candle") or key == "candle" or key.endswith("_button") or \
+            key == "lever" or key.endswith("_head") or key.endswith("_skull") or key == "flower_pot" or key.startswith("potted_"):
+        return ("small",)
+    return ("cube",)
+
+
+def _model_boxes(cls):
+    """AABB boxes (xmin, xmax, ymin, ymax, zmin, zmax) of a model class — Minecraft's familiar shapes."""
+    kind = cls[0]
+    if kind == "slab":
+        return {"bottom": [(0, 1, 0, 0.5, 0, 1)], "top": [(0, 1, 0.5, 1, 0, 1)]}.get(cls[1])   # "double" -> None: a full cube
+    if kind == "stairs":
+        lo, hi = ((0, 0.5), (0.5, 1)) if cls[1] == "bottom" else ((0.5, 1), (0, 0.5))
+        step = {"east": (0.5, 1, hi[0], hi[1], 0, 1), "west": (0, 0.5, hi[0], hi[1], 0, 1),
+                "south": (0, 1, hi[0], hi[1], 0.5, 1), "north": (0, 1, hi[0], hi[1], 0, 0.5)}[cls[2] if cls[2] in ("east", "west", "south", "north") else "north"]
+        return [(0, 1, lo[0], lo[1], 0, 1), step]
+    if kind == "thin":
+        t = cls[1]
+        return [(0, 1, 1 - t, 1, 0, 1)] if cls[2] == "top" else [(0, 1, 0, t, 0, 1)]
+    if kind == "door":
+        t = cls[2]
+        return [{"north": (0, 1, 0, 1, 1 - t, 1), "south": (0, 1, 0, 1, 0, t), "west": (1 - t, 1, 0, 1, 0, 1), "east": (0, t, 0, 1, 0, 1)}
+                .get(cls[1], (0, 1, 0, 1, 0, t))]
+    if kind == "post":
+        h, sides, fence = cls[1], cls[2], cls[3]
+        boxes = [(0.5 - h, 0.5 + h, 0, 1, 0.5 - h, 0.5 + h)]
+        y0, y1, w = (0.375, 0.9375, 0.0625) if fence else (0.0, 0.875 if h == 0.25 else 1.0, 0.1875 if h == 0.25 else 0.0625)
+        arm = {"north": (0.5 - w, 0.5 + w, y0, y1, 0, 0.5 - h), "south": (0.5 - w, 0.5 + w, y0, y1, 0.5 + h, 1),
+               "west": (0, 0.5 - h, y0, y1, 0.5 - w, 0.5 + w), "east": (0.5 + h, 1, y0, y1, 0.5 - w, 0.5 + w)}
+        return boxes + [arm[d] for d in sides]
+    if kind == "small":
+        return [(0.375, 0.625, 0, 0.625, 0.375, 0.625)]
+    return None
+
+
+def asset_pack(palette: List[dict], emitters: bool = False):
+    """(Palettes, atlas, texture records incl. the sun's at [-1]) for an `.octree2` block palette."""
+    names = []
+    for blk in palette:
+        n = blk.get("Name", "minecraft:air")
+        if n not in names:
+            names.append(n)
+    tiles = int(math.ceil(math.sqrt(len(names) + 8)))
+    ab = scenes.AtlasBuilder(tiles, tiles)
+    tex = {}
+    for n in names:
+        key = n.split(":")[-1]
+        argb = _block_color(n)
+        rgb = ((argb >> 16) & 255, (argb >> 8) & 255, argb & 255)
+        cls = _model_class(key, {})
+        holes = 0.45 if cls[0] == "plant" else (0.2 if key.endswith("_leaves") or key in ("cobweb", "iron_bars") or key.endswith("glass_pane") else 0.0)
+        tex[n] = ab.add(scenes.noise_texture(np.random.default_rng(zlib.crc32(n.encode())), rgb, 18, holes=holes))
+    tsun = ab.add(scenes.noise_texture(np.random.default_rng(1), (255, 250, 230), 4, size=32))
+    atlas, recs = ab.build()
+    pal = scenes.Palettes()
+    mat = {}
+    models = {}   # model class -> pointer into the AABB / quad palette (entries of one class and material share a model)
+    for blk in palette:
+        n = blk.get("Name", "minecraft:air")
+        if n in INVISIBLE:
+            pal.block_invisible()
+            continue
+        key = n.split(":")[-1]
+        if n not in mat:
+            glow = any(k in key for k in ("lantern", "glowstone", "torch", "lamp", "lava", "sea_pickle", "shroomlight", "magma"))
+            tint = (1 << 24) if key.endswith("_leaves") or key == "vine" else ((2 << 24) if key in ("grass", "tall_grass", "fern", "large_fern") else 0)
+            mat[n] = pal.material(texture=recs[tex[n]], tint=tint, emittance=1.0 if emitters and glow else 0.0)
+        m = mat[n]
+        cls = _model_class(key, blk.get("Properties", {}) or {})
+        if cls[0] == "plant":
+            if (cls, m) not in models:
+                def quad(o, xv, yv):
+                    return (o, xv, yv, (0.0, 1.0, 0.0, 1.0), m, 1)
+                pal.block_quads([quad((0.15, 0, 0.15), (0.7, 0, 0.7), (0, 1, 0)), quad((0.85, 0, 0.85), (-0.7, 0, -0.7), (0, 1, 0)),
+                                 quad((0.15, 0, 0.85), (0.7, 0, -0.7), (0, 1, 0)), quad((0.85, 0, 0.15), (-0.7, 0, 0.7), (0, 1, 0))])
+                models[(cls, m)] = tuple(pal.blocks[-2:])
+            else:
+                pal.blocks += list(models[(cls, m)])
+            continue
+        boxes = _model_boxes(cls)
+        if boxes is None:
+            pal.block_cube(m)
+        elif (cls, m) not in models:
+            pal.block_aabbs([(b, 0, (m,) * 6) for b in boxes])
+            models[(cls, m)] = tuple(pal.blocks[-2:])
+        else:
+            pal.blocks += list(models[(cls, m)])
+    return pal, atlas, recs, tsun
+
 
 def camera_from_json(cam: dict, origin=(0.0, 0.0, 0.0)) -> np.ndarray:
     """15 camera floats (`ClCamera.java:42-52`) from Chunky's scene JSON camera block: position minus
@@ -210,16 +337,10 @@ def camera_from_json(cam: dict, origin=(0.0, 0.0, 0.0)) -> np.ndarray:
 
 def load_scene(octree2_path: str, json_path: str = None, width: int = 1920, height: int = 1080,
                emitters: bool = False) -> scenes.PackedScene:
-    """`.octree2` (+ scene JSON for camera / sun) -> PackedScene with procedural flat-colour cubes."""
+    """`.octree2` (+ scene JSON for camera / sun) -> PackedScene through the procedural asset pack (`asset_pack`: model classes
+    from names and properties, one hashed 16 x 16 texture per block name); `flat=True` in the environment of old fixtures is gone."""
     palette, depth, stream = read_octree2(octree2_path)
-    pal = scenes.Palettes()
-    for blk in palette:
-        name = blk.get("Name", "minecraft:air")
-        if name in INVISIBLE:
-            pal.block_invisible()
-        else:
-            emit = 1.0 if emitters and any(k in name for k in ("lantern", "glowstone", "torch", "lamp")) else 0.0
-            pal.block_cube(pal.material(argb=_block_color(name), emittance=emit))
+    pal, atlas, recs, tsun = asset_pack(palette, emitters)
     tree = pack_preorder(stream, len(palette))
     blocks, mats, aabbs, quads = pal.arrays()
     alt, azi, inten, draw = 0.6, 1.2, 1.25, True
@@ -237,10 +358,6 @@ def load_scene(octree2_path: str, json_path: str = None, width: int = 1920, heig
             oz = 16 * min(c[1] for c in chunks)
             origin = (float(ox), float(js.get("yMin", 0)), float(oz))
             cam = camera_from_json(js["camera"], origin)
-    rng = np.random.default_rng(1)
-    ab = scenes.AtlasBuilder(2, 2)
-    tsun = ab.add(scenes.noise_texture(rng, (255, 250, 230), 4, size=32))
-    atlas, recs = ab.build()
     return scenes.PackedScene(octree=tree, octree_depth=depth, block_palette=blocks, material_palette=mats,
                               aabb_models=aabbs, quad_models=quads, world_bvh=scenes.empty_bvh(),
                               actor_bvh=scenes.empty_bvh(), bvh_trigs=np.zeros(1, np.int32), atlas=atlas,

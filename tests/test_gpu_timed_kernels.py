@@ -225,7 +225,7 @@ def test_city_with_its_entities(gpu_instance, port):
 
 def test_config0_plumbing_image(gpu_instance, port):
     """BASELINE configs[0] — benchmark/OpenCL_test at 256x256, 16 spp (recorded on the CPU path by tools/config0_cpu.py,
-    profiles/r02_config0_cpu.json): the whole image from the HIP path equals the CPU path's, bit for bit."""
+    profiles/r05_config0_cpu.json): the whole image from the HIP path equals the CPU path's, bit for bit."""
     from chunkyclplugin_amd import octree2
     sc = octree2.cached_benchmark_scene(256, 256)
     seeds = native.java_random_ints(16)

@@ -2,7 +2,7 @@
 """BASELINE.json configs[0]: the reference's benchmark/OpenCL_test scene on the CPU path, 256x256, 16 spp — the plumbing
 configuration (no GPU).  Chunky's own Java PathTracingRenderer cannot run here (no JDK / chunky-core jar), so the CPU path
 is the C restatement of the reference kernel (oracle/port.c, OpenMP) and, where it was built, the reference kernel itself
-compiled for x86-64 (oracle/_ref); both render the same image bit for bit.  Writes profiles/r02_config0_cpu.json."""
+compiled for x86-64 (oracle/_ref); both render the same image bit for bit.  Writes profiles/r05_config0_cpu.json."""
 import hashlib
 import json
 import os
@@ -19,7 +19,7 @@ from oracle import binding  # noqa: E402
 sc = octree2.cached_benchmark_scene(256, 256)
 seeds = scenes.java_random_ints(16)
 threads = binding.usable_threads()
-out = {"config": "BASELINE configs[0]: benchmark/OpenCL_test, 256x256, 16 spp, sun+sky, flat-colour cubes (octree2.py)",
+out = {"config": "BASELINE configs[0]: benchmark/OpenCL_test, 256x256, 16 spp, sun+sky, procedural asset pack (octree2.py: block models by name and properties, hashed 16x16 textures)",
        "host_threads": threads, "samples": 256 * 256 * 16}
 h = binding.SceneHandle(sc)
 t0 = time.perf_counter()
@@ -35,4 +35,4 @@ if ref is not None:
     out["reference_kernel_x86"] = {"seconds": round(dt, 3), "Msamples/s": round(256 * 256 * 16 / dt / 1e6, 4),
                                    "bit_identical_to_port": bool(np.array_equal(res.view(np.uint32), res2.view(np.uint32)))}
 print(json.dumps(out, indent=1))
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_config0_cpu.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r05_config0_cpu.json"), "w"), indent=1)
