@@ -123,3 +123,44 @@ def test_octree2_reader_on_the_reference_benchmark_scene():
     # first leaf cell of the stream round-trips through the packed layout
     sc = octree2.cached_benchmark_scene(64, 36)
     assert sc.octree.size == tree.size and sc.octree_depth == 10
+
+
+def test_asset_pack_gives_palette_entries_their_model_class():
+    """octree2.asset_pack (row f1): a palette entry's NAME and PROPERTIES decide its model — the geometry Minecraft gives the
+    class — and every block name gets one texture; entries of one class and material share a model."""
+    from chunkyclplugin_amd import octree2
+    cls, boxes = octree2._model_class, octree2._model_boxes
+    assert boxes(cls("stone_brick_slab", {"type": "top"})) == [(0, 1, 0.5, 1, 0, 1)]
+    assert boxes(cls("stone_brick_slab", {"type": "double"})) is None                       # a full cube
+    assert boxes(cls("spruce_stairs", {"half": "bottom", "facing": "east"})) == [(0, 1, 0, 0.5, 0, 1), (0.5, 1, 0.5, 1, 0, 1)]
+    assert boxes(cls("spruce_stairs", {"half": "top", "facing": "north"})) == [(0, 1, 0.5, 1, 0, 1), (0, 1, 0, 0.5, 0, 0.5)]
+    fence = boxes(cls("oak_fence", {"north": "true", "east": "false", "south": "false", "west": "true"}))
+    assert fence[0] == (0.375, 0.625, 0, 1, 0.375, 0.625) and len(fence) == 3               # post + two arms
+    assert boxes(cls("iron_bars", {}))[0] == (0.4375, 0.5625, 0, 1, 0.4375, 0.5625)
+    assert boxes(cls("rail", {})) == [(0, 1, 0, 0.0625, 0, 1)] and boxes(cls("oak_trapdoor", {"half": "top"})) == [(0, 1, 0.8125, 1, 0, 1)]
+    assert cls("poppy", {}) == ("plant",) and cls("stone", {}) == ("cube",) and boxes(cls("stone", {})) is None
+    palette = [{"Name": "minecraft:air"}, {"Name": "minecraft:stone"}, {"Name": "minecraft:oak_slab", "Properties": {"type": "bottom"}},
+               {"Name": "minecraft:oak_slab", "Properties": {"type": "bottom", "waterlogged": "true"}}, {"Name": "minecraft:poppy"},
+               {"Name": "minecraft:oak_slab", "Properties": {"type": "double"}}]
+    pal, atlas, recs, tsun = octree2.asset_pack(palette)
+    blocks, mats, aabbs, quads = pal.arrays()
+    b = blocks.reshape(-1, 2)
+    assert b[:, 0].tolist() == [0, 1, 2, 2, 3, 1]                                            # invisible, cube, AABB, AABB, quads, cube
+    assert b[2, 1] == b[3, 1] and aabbs[0] == 1 and quads[0] == 4                            # the two bottom slabs share one model
+    assert mats.size == 6 * 3 and (mats.reshape(-1, 6)[:, 0] == 4).all()                     # three names, all textured
+    assert atlas.shape[1] % 16 == 0 and recs[tsun][0] == (32 << 16) | 32
+
+
+def test_benchmark_fixture_is_what_the_loader_makes_of_the_reference_files():
+    """Where the reference's data files exist: the committed fixture equals load_scene's output array for array."""
+    import os
+    import pytest
+    from chunkyclplugin_amd import octree2
+    if not os.path.exists(octree2.REFERENCE_SCENE + ".octree2"):
+        pytest.skip("reference benchmark files not present on this machine")
+    made = octree2.load_scene(octree2.REFERENCE_SCENE + ".octree2", octree2.REFERENCE_SCENE + ".json")
+    kept = octree2.cached_benchmark_scene(made.width, made.height)
+    for f in ("octree", "block_palette", "material_palette", "aabb_models", "quad_models", "atlas", "sky", "sun", "camera"):
+        np.testing.assert_array_equal(np.asarray(getattr(made, f)), np.asarray(getattr(kept, f)), err_msg=f)
+    kinds = kept.block_palette.reshape(-1, 2)[:, 0]
+    assert (kinds == 2).sum() > 1000 and (kinds == 3).sum() >= 20 and (kinds == 1).sum() > 1500   # model blocks are part of the city now
