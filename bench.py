@@ -66,6 +66,125 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 MERGE_INTERVAL = 1024  # OpenClPathTracingRenderer.java:158
 
+LINE_LIMIT = 4000  # bytes of the final stdout line: the driver keeps about 8 KB of stdout, and round 5's 20 KB line was lost to it
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "\u2026"
+
+
+def compact_line(out):
+    """The ONE line the driver parses, from the full result object: the contract's keys and the few figures a reader needs,
+    nothing that grows (notes, limits, timelines, per-rank lists, transports: those are in bench_detail.json and on stderr).
+    Always shorter than LINE_LIMIT — optional objects are dropped, in order of importance, before that could fail."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+    cfg = out.get("config", {})
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    line["metric"] = _short(line["metric"], 160)
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 200), **pick(cfg, ("baseline_config", "passes_per_step", "spp_timed")),
+                      "parallelism": _short(cfg.get("parallelism", ""), 200)}
+    roof = out.get("roofline") or {}
+    r = pick(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "physical_frac", "physical_bound", "algorithmic_bytes_per_sample",
+                    "kernel", "launch_ms", "samples_per_launch"))
+    r.setdefault("traffic", None)
+    if roof.get("nearest_ceiling"):
+        r["nearest_ceiling"] = pick(roof["nearest_ceiling"], ("resource", "frac"))
+    if roof.get("pmc_source"):
+        r["pmc_source"] = _short(roof["pmc_source"], 80)
+    line["roofline"] = r
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        c = pick(cpu, ("value", "unit", "cores", "kind"))
+        if isinstance(cpu.get("restatement"), dict):
+            c["restatement_value"] = cpu["restatement"].get("value")
+        c["sample"] = _short(cpu.get("sample", ""), 150)
+        line["cpu_baseline"] = c
+    optional = []  # (key, value) in the order they are given up when the line would grow past the limit: last first
+    if out.get("image_check"):
+        optional.append(("image_check", pick(out["image_check"], ("pixels", "passes", "bit_identical"))))
+    optional.append(("rccl_ranks", out.get("rccl_ranks", 0)))
+    col = out.get("collective") or {}
+    c = pick(col, ("backend", "ranks"))
+    c.setdefault("backend", None)
+    if col.get("rccl_failed"):
+        c["rccl_failed"] = _short(col["rccl_failed"], 120)
+    if isinstance(col.get("transport"), dict):
+        c["transport"] = col["transport"].get("name")
+    optional.append(("collective", c))
+    if out.get("other_configs"):
+        legs = []
+        for leg in out["other_configs"]:
+            e = pick(leg, ("baseline_config", "value", "ms_per_step"))
+            if leg.get("roofline"):
+                e["frac"] = leg["roofline"].get("frac")
+            if leg.get("image_check"):
+                e["bit_identical"] = leg["image_check"].get("bit_identical")
+            if leg.get("error"):
+                e["error"] = _short(leg["error"], 100)
+            legs.append(e)
+        optional.append(("other_configs", legs))
+    for k in ("value_hbm_resident", "gpu_over_cpu", "emulated_world"):
+        if out.get(k) is not None:
+            optional.append((k, out[k]))
+    if isinstance(out.get("end_to_end"), dict):
+        optional.append(("end_to_end", pick(out["end_to_end"], ("value", "cold_value", "spp", "error"))))
+    if out.get("per_rank"):
+        km = out["per_rank"].get("kernel_ms") or [0.0]
+        rm = [x for xs in out["per_rank"].get("reduce_ms", []) for x in xs] or [0.0]
+        optional.append(("per_rank", {"kernel_ms_min": min(km), "kernel_ms_max": max(km), "reduce_ms_max": max(rm)}))
+    if isinstance(out.get("group_check"), dict):
+        g = out["group_check"]
+        e = pick(g, ("members", "value", "render_ms", "gather_ms"))
+        if isinstance(g.get("transport"), dict):
+            e["transport"] = g["transport"].get("name")
+        if isinstance(g.get("image_check"), dict):
+            e["bit_identical"] = g["image_check"].get("bit_identical")
+        if isinstance(g.get("transports_checked"), dict):
+            e["transports_bit_identical"] = {k: v.get("bit_identical") for k, v in g["transports_checked"].items() if isinstance(v, dict)}
+        if g.get("error"):
+            e["error"] = _short(g["error"], 120)
+        optional.append(("group_check", e))
+    for k in ("extension_behind_cull", "extension_emitter_nee"):
+        if isinstance(out.get(k), dict):
+            e = pick(out[k], ("value",))
+            if isinstance(out[k].get("image_check"), dict):
+                e["bit_identical"] = out[k]["image_check"].get("bit_identical")
+            optional.append((k, e))
+    if isinstance(out.get("bigworld"), dict):
+        optional.append(("bigworld", pick(out["bigworld"], ("value", "bit_identical", "error"))))
+    optional.append(("detail", out.get("detail_file", "bench_detail.json")))
+    for k, v in optional:
+        line[k] = v
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text.encode()) >= LINE_LIMIT and optional:
+        k, _ = optional.pop()
+        line.pop(k, None)
+        line["dropped"] = line.get("dropped", []) + [k]
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(out, detail_path=""):
+    """Full object -> the detail file (default: bench_detail.json beside this script, + gpurun_out/ when that exists) and stderr;
+    compact line -> stdout, LAST."""
+    paths = [detail_path] if detail_path else [os.path.join(d, "bench_detail.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    out["detail_file"] = os.path.basename(paths[0]) if paths else None
+    full = json.dumps(out, indent=1)
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                f.write(full + "\n")
+        except OSError as e:
+            print(f"bench.py: could not write {p}: {e}", file=sys.stderr)
+    print("bench.py: full result object (also in bench_detail.json):\n" + json.dumps(out), file=sys.stderr, flush=True)
+    text = compact_line(out)
+    assert len(text.encode()) < LINE_LIMIT, len(text)
+    print(text, flush=True)
+
 
 def workload(config: int, args):
     """(scene, passes per step, name of its rows in tests/golden/timed_rows.npz, description, spp of the end-to-end leg)."""
@@ -239,6 +358,18 @@ def nearest_ceiling(pm, physical_frac):
                     "`frac` above is a work-rate convention; this is the hardware view"}
 
 
+def physical_bound(pm, physical_frac):
+    """What binds the kernel on the HARDWARE, beside the contract's "bound": "hbm" (a work-rate convention): the fullest resource
+    when one is above 80 % of its rate, else "latency" (no unit saturated, waves waiting: paths in flight x latency), or
+    "issue+latency" when the VALU issue slots are the fullest unit and more than half used."""
+    nc = nearest_ceiling(pm, physical_frac)
+    if not nc:
+        return None
+    if nc["frac"] >= 0.8:
+        return nc["resource"]
+    return "issue+latency" if nc["resource"] in ("valu_issue", "scalar_pipe") and nc["frac"] >= 0.5 else "latency"
+
+
 def roofline_object(sc, config, info, launch_ms, launches, samples_per_launch, passes_per_launch, seeds, threads, n_rows, kernel_variant,
                     attach_pmc=True, build_oracle=True):
     """The contract roofline of one measured leg + what the committed PMC entry of this launch shape says."""
@@ -259,6 +390,7 @@ def roofline_object(sc, config, info, launch_ms, launches, samples_per_launch, p
             "frac_above_one": bool(frac > 1.0),
             "physical_frac": round(physical, 5) if physical is not None else None,
             "nearest_ceiling": nearest_ceiling(pm, physical),
+            "physical_bound": physical_bound(pm, physical),
             "valu": pm.get("valu") if pm else None, "limits": pm.get("limits") if pm else None,
             "pmc_source": pm.get("source") if pm else None, "pmc_collected": pm.get("collected") if pm else None,
             "algorithmic_bytes_per_sample": round(bytes_per_sample, 1) if bytes_per_sample else None,
@@ -422,6 +554,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of BASELINE configs[1], [3], [4] in the default line")
     ap.add_argument("--group", type=int, default=0, help="N > 0: ONE process, N GPUs behind one context (chunky_group_create); "
                                                          "members share GPU 0 when the box has fewer than N")
+    ap.add_argument("--detail", default="", help="where the FULL result object goes (default: bench_detail.json beside this script); stdout "
+                                                 "carries only the compact line (< 4000 bytes)")
     ap.add_argument("--dump", default="", help="rank 0 writes the final (reduced) framebuffer to this .npy file")
     ap.add_argument("--emulate-world", type=int, default=0, help="rig: render only rank 0's share of an N-GPU split on one GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for rigs")
@@ -881,7 +1015,7 @@ def main():
             out["cpu_baseline"]["chunky_java_renderer"] = (
                 "unavailable: " + ("no JDK (`java` not on PATH)" if not shutil.which("java") else "a JDK but no chunky-core jar") + " on this box"
                 if not (shutil.which("java") and jars) else f"found {jars[0]} (not driven by this bench)")
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
         # the line is the LAST thing on stdout: whatever a native library prints while it shuts down (RCCL announces itself on
         # stdout) goes to stderr from here on
         try:

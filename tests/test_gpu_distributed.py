@@ -36,14 +36,32 @@ def _run_bench(world, dump, extra=(), launcher=True, steps=1, passes=PASSES, sma
     launch = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] if launcher else [sys.executable])
     size = ["--passes", str(passes), "--width", str(W), "--height", str(H), "--chunks", str(CHUNKS)] if small else []
+    detail = dump + ".detail.json"
     cmd = [*launch, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "0",
-           *size, "--one-device", "--backend", backend, "--no-cpu", "--dump", dump, *extra]
+           *size, "--one-device", "--backend", backend, "--no-cpu", "--dump", dump, "--detail", detail, *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE JSON line
-    return json.loads(lines[0])
+    return _line_and_detail(p.stdout, detail)
+
+
+def _line_and_detail(stdout, detail):
+    """The ONE stdout line must stay inside what the driver keeps of stdout (round 5's 20 KB line was lost); everything else is
+    in the detail file.  Returns the detail object after checking that the line is its summary."""
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]          # rank 0 prints ONE JSON line
+    assert len(lines[0].encode()) < 4000, len(lines[0])
+    line, full = json.loads(lines[0]), json.load(open(detail))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k], k
+    assert "dropped" not in line, line["dropped"]
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["launch_ms"] == full["roofline"]["launch_ms"]
+    assert line["config"]["workload"] and line["collective"]["ranks"] == full["collective"]["ranks"] and line["rccl_ranks"] == full["rccl_ranks"]
+    if "image_check" in full:
+        assert line["image_check"]["bit_identical"] == full["image_check"]["bit_identical"]
+    if "other_configs" in full:
+        assert [o["baseline_config"] for o in line["other_configs"]] == [o["baseline_config"] for o in full["other_configs"]]
+    return full
 
 
 @pytest.fixture(scope="module")
@@ -132,13 +150,14 @@ def test_headline_line_checks_its_own_image(tmp_path):
 
 
 def _run_single(args):
+    import tempfile
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", *args],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as td:
+        detail = os.path.join(td, "detail.json")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu", "--detail", detail, *args],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return _line_and_detail(p.stdout, detail)
 
 
 def test_group_mode_of_the_bench():
