@@ -200,6 +200,10 @@ def workload(config: int, args):
         base = scenes.cached_outdoor_world(chunks=32, height=256)
         sc = scenes.add_entities(base, 100000, seed=11, actor_tris=5000, region=((40, 90, 40), (470, 170, 470))).with_view(3840, 2160)
         return sc, 16, "entities4k", "BASELINE configs[4]: 32x32-chunk world + 100 000 world / 5 000 actor triangles (entity BVHs)", 64
+    if config == 5:
+        sc = scenes.cached_big_outdoor_world(width=args.width, img_height=args.height)
+        return sc, 64, None, ("NOT a BASELINE configuration: 128x128-chunk outdoor world (2048 x 256 x 2048 blocks, depth-11 octree; its re-laid-out "
+                              "tree is 367 MB: beyond the 256 MiB Infinity Cache)"), 256
     sc = scenes.cached_outdoor_world(chunks=args.chunks, height=256, width=args.width, img_height=args.height)
     golden = "outdoor" if (args.chunks, args.width, args.height) == (32, 1920, 1080) else None
     return sc, 256, golden, f"BASELINE configs[2]: synthetic {args.chunks}x{args.chunks}-chunk outdoor world", 1024
@@ -269,7 +273,7 @@ def golden_rows(name):
     return g["seeds"], g[name + "_rows"], g[name + "_res"]
 
 
-def compare_golden(image, gold, width):
+def compare_golden(image, gold, width, against="tests/golden/timed_rows.npz (rows rendered by the reference build, oracle/_ref)"):
     """image: float32 [3*W*H] (the read-back); gold from golden_rows.  -> the image_check object."""
     _, rows, want = gold
     img = image.reshape(-1, width, 3)
@@ -279,7 +283,20 @@ def compare_golden(image, gold, width):
         rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-6)
     return {"rows": [int(y) for y in rows], "pixels": int(same.size), "pixels_differing": int((~same).sum()),
             "bit_identical": bool(same.all()), "max_rel_err": float(np.nanmax(rel)) if rel.size else 0.0,
-            "passes": int(len(gold[0])), "against": "tests/golden/timed_rows.npz (rows rendered by the reference build, oracle/_ref)"}
+            "passes": int(len(gold[0])), "against": against}
+
+
+def live_golden(sc, n_rows=12, n_passes=4):
+    """For a view without reference-rendered rows in tests/golden: whole rows rendered HERE by the CPU oracle (oracle/port.c, the C
+    restatement — bit-identical to the reference build on every scene tried), in golden_rows' shape."""
+    from oracle import binding
+    from chunkyclplugin_amd import native
+    port = binding.port()
+    seeds = native.java_random_ints(n_passes)
+    rows = sample_rows(sc.height, n_rows)
+    gids = (np.asarray(rows, np.int64)[:, None] * sc.width + np.arange(sc.width)[None, :]).reshape(-1).astype(np.int32)
+    res = port.render_gids(binding.SceneHandle(sc), seeds, gids, threads=usable_cpus()[0])
+    return seeds, np.asarray(rows), res.reshape(-1, sc.width, 3)[np.asarray(rows)].copy()
 
 
 def pmc_entry(config, info, passes_per_launch, samples_per_launch, kernel_variant):
@@ -539,7 +556,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4), help="BASELINE.json configs[n] (default 2: the headline)")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4, 5), help="BASELINE.json configs[n] (default 2: the headline); 5 = the beyond-cache "
+                                                                                   "world (not a BASELINE configuration: how the design degrades when the tree leaves the caches)")
     ap.add_argument("--passes", type=int, default=0, help="passes (spp) per step; 0 = the configuration's (256 for the headline: the most a launch carries)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -609,6 +627,8 @@ def main():
         passes = args.passes
     n_pix = sc.width * sc.height
     gold = golden_rows(golden_name)
+    if gold is None and args.config == 5 and not args.no_extras and not args.no_roofline:
+        gold = live_golden(sc)   # (before the GPU is busy: a few seconds of the host's cores)
     group_devices = None
     if args.group > 0:
         n_dev = RendererInstance.device_count()
@@ -760,7 +780,8 @@ def main():
         r.render_passes(gold[0], sync=False)
         read_back()
         if rank == 0:
-            image_check = compare_golden(r.read() if group_devices else image.cpu().numpy(), gold, sc.width)
+            image_check = compare_golden(r.read() if group_devices else image.cpu().numpy(), gold, sc.width,
+                                         **({"against": "rows rendered in this run by oracle/port.c (the C restatement of the reference kernel)"} if args.config == 5 else {}))
     if world > 1:
         dist.barrier(group=ctl)
 
@@ -861,7 +882,9 @@ def main():
         box = {"hostname": os.uname().nodename, "gpu": inst.device_name() if not group_devices else torch.cuda.get_device_name(local_rank),
                "gpus_visible": torch.cuda.device_count()}
         out = {
-            "metric": "Msamples/s, 32x32-chunk scene @1920x1080" if args.config == 2 else f"Msamples/s, BASELINE configs[{args.config}] @{sc.width}x{sc.height}",
+            "metric": "Msamples/s, 32x32-chunk scene @1920x1080" if args.config == 2 else
+                      (f"Msamples/s, beyond-cache world (not a BASELINE configuration) @{sc.width}x{sc.height}" if args.config == 5 else
+                       f"Msamples/s, BASELINE configs[{args.config}] @{sc.width}x{sc.height}"),
             "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": len(group_devices) if group_devices else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),

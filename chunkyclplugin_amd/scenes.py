@@ -768,6 +768,159 @@ def cached_outdoor_world(**kw) -> PackedScene:
     return sc
 
 
+
+# ------------------------------------------------------------------------------- a world beyond the caches
+def build_octree_slab(t: np.ndarray, depth: int, any_code: int) -> np.ndarray:
+    """build_octree(order="bfs") for a world that is a SLAB: `t` is [n, h, n] (n = 2**depth, h a power of two <= n) of small
+    block-palette indices (int16; `any_code` stands for ANY_TYPE), everything above y = h is air.  Same layout, same merging,
+    same breadth-first group numbering as build_octree on the dense [n, n, n] array — which for a 2048-wide world would be
+    34 GB — built from the slab's own halvings; from the level where the slab is one cell thick it is padded with air."""
+    n, h = t.shape[0], t.shape[1]
+    assert t.shape == (n, h, n) and n == 1 << depth and h & (h - 1) == 0 and h <= n and t.dtype == np.int16
+    BR = -1
+    levels = [t]
+    for _ in range(depth):
+        c = levels[-1]
+        if c.shape[1] == 1 and c.shape[0] > 1:  # the slab is one cell thick here: the cells above it are air
+            full = np.zeros((c.shape[0],) * 3, np.int16)
+            full[:, 0, :] = c[:, 0, :]
+            c = full
+        a, b = c.shape[0] // 2, c.shape[1] // 2
+        v = c.reshape(a, 2, b, 2, a, 2).transpose(0, 2, 4, 1, 3, 5).reshape(a, b, a, 8)
+        first = v[..., 0]
+        same = (v == first[..., None]).all(axis=-1) & (first != BR)
+        levels.append(np.where(same, first, BR).astype(np.int16))
+
+    def leaf_value(x: np.ndarray) -> np.ndarray:
+        x = x.astype(np.int64)
+        return np.where(x == any_code, -ANY_TYPE, -2 * x)
+
+    def at(level: np.ndarray, cc: np.ndarray) -> np.ndarray:  # cells above the slab are air
+        hh = level.shape[1]
+        ok = cc[:, 1] < hh
+        out = np.zeros(len(cc), np.int64)
+        out[ok] = level[cc[ok, 0], cc[ok, 1], cc[ok, 2]]
+        return out
+
+    root = int(levels[depth][0, 0, 0])
+    if root != BR:
+        return np.array([int(leaf_value(np.array([root]))[0])], np.int32)
+    n_branch = sum(int((l == BR).sum()) for l in levels[1:])
+    data = np.zeros(1 + 8 * n_branch, np.int64)
+    data[0] = 1
+    coords = np.zeros((1, 3), np.int64)
+    bases = np.array([1], np.int64)
+    nxt = 9
+    offs = np.array([[(s >> 2) & 1, (s >> 1) & 1, s & 1] for s in range(8)], np.int64)
+    for lvl in range(depth, 0, -1):
+        cc = (coords[:, None, :] * 2 + offs[None, :, :]).reshape(-1, 3)
+        vals = at(levels[lvl - 1], cc)
+        slots = (bases[:, None] + np.arange(8)[None, :]).reshape(-1)
+        isb = vals == BR
+        nb = int(isb.sum())
+        newbases = nxt + 8 * np.arange(nb, dtype=np.int64)
+        out = leaf_value(vals)
+        out[isb] = newbases
+        data[slots] = out
+        coords, bases = cc[isb], newbases
+        nxt += 8 * nb
+        if nb == 0:
+            break
+    assert nxt == len(data)
+    return data.astype(np.int32)
+
+
+def big_outdoor_world(chunks: int = 128, height: int = 256, seed: int = 20260606, width: int = 1920, img_height: int = 1080) -> PackedScene:
+    """A world whose trees do NOT fit the 256 MiB Infinity Cache (bench.py --config 5; not a BASELINE configuration): chunks x chunks
+    chunks of the outdoor world's kind — the same palettes, textures, sky and sun (taken from outdoor_world itself), value-noise
+    terrain with the same layers, slabs / posts / plants on the surface, hidden interior as ANY_TYPE — 2048 x 256 x 2048 blocks in a
+    depth-11 octree at the default size."""
+    small = outdoor_world(chunks=1, height=16, width=width, img_height=img_height)
+    names = ("air", "bedrock", "stone", "dirt", "grass", "sand", "log", "leaves", "plank", "glow", "snow", "flat", "slab", "post", "plant")
+    B = {k: i for i, k in enumerate(names)}   # outdoor_world's block order (asserted below through the palette's model types)
+    assert len(small.block_palette) == 2 * len(names) and list(small.block_palette[2 * B["slab"]::2][:3]) == [2, 2, 3]
+    ANY = 255
+    rng = np.random.default_rng(seed)
+    n = chunks * 16
+    depth = int(math.ceil(math.log2(max(n, height))))
+    assert n == 1 << depth and height & (height - 1) == 0, "chunks x 16 and the height have to be powers of two"
+    hmap = value_noise2(rng, n, octaves=5, base=max(n // 8, 8))
+    lo_h, hi_h = 0.19 * height, 0.55 * height
+    hgt = (lo_h + (hi_h - lo_h) * hmap).astype(np.int16)
+    t = np.zeros((n, height, n), np.int16)
+    ys = np.arange(height, dtype=np.int16)[None, :, None]
+    H3 = hgt[:, None, :]
+    t[ys <= H3] = B["stone"]
+    t[(ys <= H3) & (ys > H3 - 4)] = B["dirt"]
+    beach = H3 < lo_h + 0.08 * (hi_h - lo_h)
+    peak = H3 > lo_h + 0.85 * (hi_h - lo_h)
+    t[ys == H3] = B["grass"]
+    t[(ys <= H3) & (ys > H3 - 3) & beach] = B["sand"]
+    t[(ys == H3) & peak] = B["snow"]
+    t[:, 0, :] = B["bedrock"]
+    r = rng.random((n, n))
+    xs, zs = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    top = hgt.astype(np.int64) + 1
+
+    def place(mask, block):
+        t[xs[mask], top[mask], zs[mask]] = block
+
+    place(r < 0.012, B["slab"])
+    place((r >= 0.012) & (r < 0.02), B["post"])
+    place((r >= 0.02) & (r < 0.03), B["plant"])
+    tr = (r >= 0.9) & (r < 0.9035) & (xs > 3) & (xs < n - 4) & (zs > 3) & (zs < n - 4) & ~beach[:, 0, :]
+    for x, z in zip(xs[tr], zs[tr]):
+        y0 = int(top[x, z])
+        th = 4 + int(rng.integers(0, 3))
+        t[x - 2:x + 3, y0 + th - 2:y0 + th, z - 2:z + 3] = B["leaves"]
+        t[x - 1:x + 2, y0 + th:y0 + th + 2, z - 1:z + 2] = B["leaves"]
+        t[x, y0:y0 + th, z] = B["log"]
+    # hidden interior (hide_interior, on the slab: the cells above it are air, so its top layer is never hidden)
+    opaque = np.zeros(256, bool)
+    for k in ("bedrock", "stone", "dirt", "grass", "sand", "log", "plank", "glow", "snow", "flat"):
+        opaque[B[k]] = True
+    op = opaque[t]
+    inner = op.copy()
+    for ax in range(3):
+        for sh in (1, -1):
+            rr = np.roll(op, sh, axis=ax)
+            sl = [slice(None)] * 3
+            sl[ax] = 0 if sh == 1 else -1
+            rr[tuple(sl)] = False
+            inner &= rr
+    t[inner] = ANY
+    del op, inner
+    octree = build_octree_slab(t, depth, ANY)
+    cam = look_at_camera((n * 0.18, hi_h + 0.20 * height, n * 0.15), (n / 2, lo_h + 0.3 * (hi_h - lo_h), n * 0.55), fov_deg=70.0)
+    return PackedScene(octree=octree, octree_depth=depth, block_palette=small.block_palette, material_palette=small.material_palette,
+                       aabb_models=small.aabb_models, quad_models=small.quad_models, world_bvh=empty_bvh(), actor_bvh=empty_bvh(),
+                       bvh_trigs=np.zeros(1, np.int32), atlas=small.atlas, sky=small.sky, sky_intensity=small.sky_intensity, sun=small.sun,
+                       camera=cam, width=width, height=img_height, name=f"bigworld{chunks}x{chunks}")
+
+
+def cached_big_outdoor_world(**kw) -> PackedScene:
+    """big_outdoor_world(**kw) through the on-disk cache (a few minutes and ~12 GB of numpy to generate at 128 x 128 chunks)."""
+    import hashlib
+    import inspect
+    import os
+    bound = inspect.signature(big_outdoor_world).bind(**kw)
+    bound.apply_defaults()
+    src = inspect.getsource(big_outdoor_world) + inspect.getsource(build_octree_slab) + inspect.getsource(outdoor_world)
+    key = hashlib.sha256((repr(sorted(bound.arguments.items())) + src).encode()).hexdigest()[:16]
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".scene_cache", f"bigworld_{key}.npz")
+    if os.path.exists(path):
+        try:
+            return load_scene(path)
+        except Exception:
+            pass
+    sc = big_outdoor_world(**kw)
+    try:
+        save_scene(sc, path)
+    except OSError:
+        pass
+    return sc
+
+
 def cached_entity_world(n_world_tris: int, actor_tris: int = 5000, seed: int = 11, region=((40, 90, 40), (470, 170, 470)), **world_kw) -> PackedScene:
     """BASELINE configs[4]: cached_outdoor_world(chunks=32, height=256, **world_kw) + add_entities(...) through the same on-disk
     cache (building the BVH of 10^6 triangles takes about a minute of numpy)."""

@@ -36,7 +36,7 @@ def test_image_check_compares_whole_rows_bit_for_bit():
 def test_pmc_summary_is_attached_only_to_its_own_launch_shape():
     entries = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]
     by = {e["config"]: e for e in entries}
-    assert set(by) == {1, 2, 3, 4}
+    assert set(by) >= {1, 2, 3, 4}
     for c, e in by.items():
         tree, group, bvh, pool = e["kernel_info"]
         info = {"tree": tree, "group": group, "bvh": bool(bvh), "pool": pool}

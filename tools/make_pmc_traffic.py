@@ -10,7 +10,11 @@ import os
 import sys
 
 pm = json.load(open(sys.argv[1]))
-bench = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+_text = open(sys.argv[2]).read().strip()
+try:
+    bench = json.loads(_text)                      # the full result object (bench_detail.json)
+except ValueError:
+    bench = json.loads(_text.splitlines()[-1])     # ... or a file whose last line is one
 target = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
 c = {k: v["mean_per_launch"] for k, v in pm["counters"].items()}
 d = pm["derived"]
