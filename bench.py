@@ -487,7 +487,7 @@ def group_leg(devices, sc, seeds, passes, gold, kernel_variant):
         t2 = time.perf_counter()
         ms, launches = r.kernel_time()
         # the same gather once more through every transport the group can use (the first one above is the default's, warm)
-        transports = {}
+        transports, checked = {}, {}
         default_t = inst.transport()
         for t_id in (native.TRANSPORT_RCCL_SENDRECV, native.TRANSPORT_RCCL_REDUCE, native.TRANSPORT_PEER_COPY):
             try:
@@ -500,12 +500,18 @@ def group_leg(devices, sc, seeds, passes, gold, kernel_variant):
             for _ in range(3):
                 r.gather()
             transports[RendererInstance.TRANSPORT_NAMES[t_id]] = {"gather_ms": round((time.perf_counter() - ta) / 3 * 1e3, 3)}
+            if gold is not None:  # every transport must deliver the reference's image, not only the default one
+                r.reset()
+                r.render_passes(gold[0])
+                chk = compare_golden(r.read(), gold, sc.width)
+                checked[RendererInstance.TRANSPORT_NAMES[t_id]] = {k: chk[k] for k in ("pixels", "pixels_differing", "bit_identical")}
+                checked[RendererInstance.TRANSPORT_NAMES[t_id]]["transport_after"] = inst.transport()["name"]  # (a fallback mid-way would show here)
         try:
             inst.set_transport(default_t["transport"])
         except native.ChunkyHipError:
             pass
         out = {"members": len(devices), "devices": [int(d) for d in devices], "peer_status": inst.peer_status(),
-               "transport": default_t, "transports_timed": transports, "transport_after": inst.transport(),
+               "transport": default_t, "transports_timed": transports, "transports_checked": checked, "transport_after": inst.transport(),
                "peer_status_legend": "0 local (member 0's device), 1 direct (peer access enabled: xGMI), 2 staged (no peer access), < 0 = -hipError",
                "passes": passes, "render_ms": round((t1 - t0) * 1e3, 3), "gather_ms": round((t2 - t1) * 1e3, 3),
                "kernel_ms_slowest_member": round(ms, 3),
@@ -679,14 +685,11 @@ def main():
             parallel.reduce_framebuffer(image, dst=0, group=None if on_gpu else ctl)  # (without a usable RCCL: staged through the host)
             torch.cuda.synchronize()
         elif group_devices:
-            r.gather()
+            r.read(out=host_image.numpy())  # ONE call: the library's exchange, then member 0's copy to the host (timed together as the exchange)
         t1 = time.perf_counter()
-        if rank == 0:
-            if group_devices:
-                r.read(out=host_image.numpy())  # (gathered above: the second exchange inside is a few tens of microseconds)
-            else:
-                host_image.copy_(image)
-                torch.cuda.synchronize()
+        if rank == 0 and not group_devices:
+            host_image.copy_(image)
+            torch.cuda.synchronize()
         reduce_ms.append((t1 - t) * 1e3)
         d2h_ms.append((time.perf_counter() - t1) * 1e3)
 

@@ -69,7 +69,8 @@ struct chunky_ctx {
     std::vector<ncclComm_t> comms;
     int transport = CHUNKY_TRANSPORT_PEER_COPY;
     std::string transport_detail = "single device: no exchange";
-    bool self_exchange = false;  // test rigs (CHUNKY_GROUP_SELF_EXCHANGE=1): member 0's own blocks travel through the exchange too
+    bool self_exchange = false;  // test rigs (tuning builds, CHUNKY_GROUP_SELF_EXCHANGE=1): member 0's own blocks travel through the exchange too
+    int exchange_timeout_ms = 30000;  // how long an RCCL exchange may stay unfinished before its communicators are aborted (group_wait)
 };
 
 struct DevBuf {
@@ -260,21 +261,120 @@ static void group_close_rccl(chunky_ctx* g, bool abort) {
     (void)hipGetLastError();
 }
 
+// Waits until every stream of `streams` (on `devices`) has drained — WITHOUT blocking in the driver: an RCCL kernel whose peer or
+// link died never completes, hipStreamSynchronize would then never return, and the one call that unblocks such a kernel,
+// ncclCommAbort, could never be reached.  Polls hipStreamQuery and the communicators' asynchronous errors; returns CHUNKY_OK, or
+// CHUNKY_E_HIP with the reason (an error RCCL noticed by itself, or the deadline) — the caller then aborts the communicators FIRST
+// and only then synchronises.
+static int group_wait(chunky_ctx* g, const std::vector<int>& devices, const std::vector<hipStream_t>& streams) {
+    const RcclApi& api = rccl_api();
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<char> done(streams.size(), 0);
+    if (g->exchange_timeout_ms == 0)  // (rigs: every exchange counts as hung, whether or not its kernels are still running)
+        return fail(CHUNKY_E_HIP, "RCCL exchange unfinished after 0 ms (a hung collective: dead peer or link?)");
+    for (unsigned spin = 0;; spin++) {
+        bool all = true;
+        for (size_t i = 0; i < streams.size(); i++) {
+            if (done[i]) continue;
+            (void)hipSetDevice(devices[i]);
+            const hipError_t q = hipStreamQuery(streams[i]);
+            if (q == hipSuccess) {
+                done[i] = 1;
+            } else if (q == hipErrorNotReady) {
+                all = false;
+                (void)hipGetLastError();
+            } else {
+                return fail(CHUNKY_E_HIP, "hipStreamQuery on device %d: %s", devices[i], hipGetErrorString(q));
+            }
+        }
+        if ((spin & 15u) == 0u || all)  // a failure the communicator noticed by itself (a dead link, a dead peer)
+            for (size_t i = 0; i < g->comms.size(); i++) {
+                ncclResult_t async = ncclSuccess;
+                if (api.CommGetAsyncError(g->comms[i], &async) == ncclSuccess && async != ncclSuccess)
+                    return fail(CHUNKY_E_HIP, "RCCL communicator of member %zu: %s", i, api.str(async));
+            }
+        if (all) return CHUNKY_OK;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > (double)g->exchange_timeout_ms)
+            return fail(CHUNKY_E_HIP, "RCCL exchange unfinished after %d ms (a hung collective: dead peer or link?)", g->exchange_timeout_ms);
+        if (spin > 64) std::this_thread::sleep_for(std::chrono::microseconds(spin > 4096 ? 500 : 20));
+    }
+}
+
+// First contact: ONE grouped send / receive of a known pattern from every member to member 0 through the communicators just
+// created, under group_wait's deadline, and the bytes compared on the host.  RCCL stays the group's transport only if this
+// machine, this process and this library file demonstrably move the right bytes; anything else — an error code, a hang, a
+// wrong byte — is found HERE, at group creation, where the answer is "peer copies, and chunky_group_transport says why",
+// not in the middle of a render.
+static int group_probe_rccl(chunky_ctx* g) {
+    const RcclApi& api = rccl_api();
+    const size_t n = g->members.size(), count = 1024;
+    std::vector<DevBuf> send(n), recv(n);
+    std::vector<int> devices;
+    std::vector<hipStream_t> streams;
+    std::vector<float> host(count);
+    for (size_t i = 0; i < n; i++) {
+        chunky_ctx* m = g->members[i];
+        for (size_t k = 0; k < count; k++) host[k] = (float)(i * 4096 + k + 1);
+        HIP_TRY(hipSetDevice(m->device));
+        HIP_TRY(send[i].upload(host.data(), count * 4, m->stream));  // (synchronises the member's stream)
+        HIP_TRY(hipSetDevice(g->members[0]->device));
+        HIP_TRY(hipMalloc(&recv[i].p, count * 4));
+        recv[i].bytes = count * 4;
+        HIP_TRY(hipMemsetAsync(recv[i].p, 0, count * 4, g->members[0]->stream));
+        devices.push_back(m->device);
+        streams.push_back(m->stream);
+    }
+    HIP_TRY(hipSetDevice(g->members[0]->device));
+    HIP_TRY(hipStreamSynchronize(g->members[0]->stream));
+    ncclResult_t rc = api.GroupStart();
+    if (rc != ncclSuccess) return fail(CHUNKY_E_HIP, "probe: ncclGroupStart: %s", api.str(rc));
+    ncclResult_t bad = ncclSuccess;
+    const char* where = "";
+    for (size_t i = 0; i < n && bad == ncclSuccess; i++) {
+        (void)hipSetDevice(g->members[i]->device);
+        if ((bad = api.Send(send[i].p, count, ncclFloat, 0, g->comms[i], g->members[i]->stream)) != ncclSuccess) where = "ncclSend";
+        (void)hipSetDevice(g->members[0]->device);
+        if (bad == ncclSuccess && (bad = api.Recv(recv[i].p, count, ncclFloat, (int)i, g->comms[0], g->members[0]->stream)) != ncclSuccess) where = "ncclRecv";
+    }
+    rc = api.GroupEnd();  // (always: the thread's group must be closed; a partial list is dealt with by the caller's abort)
+    if (bad != ncclSuccess) return fail(CHUNKY_E_HIP, "probe: %s: %s", where, api.str(bad));
+    if (rc != ncclSuccess) return fail(CHUNKY_E_HIP, "probe: ncclGroupEnd: %s", api.str(rc));
+    if (int w = group_wait(g, devices, streams)) return w;
+    HIP_TRY(hipSetDevice(g->members[0]->device));
+    for (size_t i = 0; i < n; i++) {
+        HIP_TRY(hipMemcpy(host.data(), recv[i].p, count * 4, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < count; k++)
+            if (host[k] != (float)(i * 4096 + k + 1))
+                return fail(CHUNKY_E_HIP, "probe: member %zu's float %zu arrived as %g", i, k, (double)host[k]);
+    }
+    return CHUNKY_OK;
+}
+
 // One RCCL communicator over the members of a group (chunky_group_transport).  Never an error: without it the exchange
 // runs on peer copies and transport_detail says why.
 static void group_open_rccl(chunky_ctx* g, const int* devices, int n) {
     g->transport = CHUNKY_TRANSPORT_PEER_COPY;
-    const char* env = getenv("CHUNKY_GROUP_TRANSPORT");
-    const std::string want = env ? env : "";
+    std::string want;
+    bool try_shared = false, probe = true;
+#ifdef CHUNKY_TUNING  // rigs of tests/test_gpu_rccl_transport.py and tools/: the shipping library reads none of these
+    if (const char* env = getenv("CHUNKY_GROUP_TRANSPORT")) want = env;
     const char* self = getenv("CHUNKY_GROUP_SELF_EXCHANGE");
     g->self_exchange = self && *self && *self != '0';
+    try_shared = getenv("CHUNKY_RCCL_TRY_SHARED") != nullptr;
+    probe = getenv("CHUNKY_GROUP_NO_PROBE") == nullptr;
+    if (const char* t = getenv("CHUNKY_GROUP_TIMEOUT_MS")) {
+        const int v = atoi(t);
+        if (v >= 0 && v <= 600000) g->exchange_timeout_ms = v;
+    }
+#endif
     if (want == "peer") {
-        g->transport_detail = "peer copies: CHUNKY_GROUP_TRANSPORT=peer";
+        g->transport_detail = "peer copies: asked for by the environment";
         return;
     }
     for (int i = 0; i < n; i++)
         for (int j = 0; j < i; j++)
-            if (devices[i] == devices[j] && !(getenv("CHUNKY_RCCL_TRY_SHARED"))) {
+            if (devices[i] == devices[j] && !try_shared) {
                 // (ncclCommInitAll refuses a device list with duplicates; CHUNKY_RCCL_TRY_SHARED lets the tests watch it do so)
                 char buf[128];
                 snprintf(buf, sizeof buf, "peer copies: members %d and %d share device %d (one RCCL rank per device)", j, i, devices[i]);
@@ -294,8 +394,19 @@ static void group_open_rccl(chunky_ctx* g, const int* devices, int n) {
         g->transport_detail = std::string("peer copies: ncclCommInitAll: ") + api.str(rc);
         return;
     }
+    if (probe && group_probe_rccl(g) != CHUNKY_OK) {
+        const std::string why = tls_error;
+        group_close_rccl(g, true);  // abort first (a hung probe kernel is unblocked by nothing else), then drain
+        for (chunky_ctx* m : g->members) {
+            (void)hipSetDevice(m->device);
+            (void)hipStreamSynchronize(m->stream);
+        }
+        (void)hipGetLastError();
+        g->transport_detail = "peer copies: RCCL failed its first exchange (" + why + ")";
+        return;
+    }
     g->transport = want == "rccl-reduce" ? CHUNKY_TRANSPORT_RCCL_REDUCE : CHUNKY_TRANSPORT_RCCL_SENDRECV;
-    g->transport_detail = rccl_detail(g, g->transport);
+    g->transport_detail = rccl_detail(g, g->transport) + (probe ? "; first exchange verified" : "");
 }
 
 extern "C" int chunky_group_create(const int* devices, int n, chunky_ctx** out) {
@@ -483,6 +594,7 @@ extern "C" int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree,
     scene->wide_meta = WideTree();
     int bits[kWideMaxLevels];
     int nlev = default_wide_levels(depth, bits);
+#ifdef CHUNKY_TUNING
     if (const char* e = getenv("CHUNKY_DEBUG_WIDE_BITS")) {  // experiments: another split, e.g. "4,3,2" (16^3 top node)
         nlev = 0;
         for (const char* q = e; *q && nlev < kWideMaxLevels;) {
@@ -491,6 +603,7 @@ extern "C" int chunky_scene_set_octree(chunky_scene* scene, const int32_t* tree,
             if (*q == ',') q++;
         }
     }
+#endif
     const char* why = "";
     WideTree wt;
     if (build_wide_tree(tree, n, depth, bits, nlev, &wt, &why)) {
@@ -954,6 +1067,7 @@ static void reorder_triangles(std::vector<int32_t>* bvh_rec, std::vector<int32_t
 static void bvh_layout_params(int* top, int* treelet) {
     *top = CHUNKY_BVH_TOP_RECORDS;
     *treelet = CHUNKY_BVH_TREELET_RECORDS;
+#ifdef CHUNKY_TUNING
     if (const char* e = getenv("CHUNKY_BVH_LAYOUT")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0) {
@@ -961,6 +1075,7 @@ static void bvh_layout_params(int* top, int* treelet) {
             *treelet = b;
         }
     }
+#endif
 }
 
 static bool build_bvh_records(const chunky_scene* s, std::vector<int32_t>* bvh_rec, std::vector<int32_t>* tri_rec, int* world_root,
@@ -1541,9 +1656,9 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
             // from a pinned slot of the target's own (the caller may reuse or free `seeds` as soon as this call returns — the JNI
             // glue releases the Java array — and a copy out of pageable memory is only safe if the runtime happens to stage it)
             chunky_render::SeedSlot& slot = r->seed_ring[r->seed_next++ % chunky_render::kSeedSlots];
-            if (!slot.host) {
+            if (!slot.host) {  // the event first: a slot is only ever seen with both or with neither
+                if (!slot.copied) HIP_TRY(hipEventCreateWithFlags(&slot.copied, hipEventDisableTiming));
                 HIP_TRY(hipHostMalloc((void**)&slot.host, (size_t)kMaxPoolPasses * 4, hipHostMallocDefault));
-                HIP_TRY(hipEventCreateWithFlags(&slot.copied, hipEventDisableTiming));
             } else {
                 HIP_TRY(hipEventSynchronize(slot.copied));  // the copy that read this slot last (kSeedSlots launches ago)
             }
@@ -1629,15 +1744,9 @@ static int group_gather_peer(chunky_render* r) {
     return gather_scatter(r, 1);
 }
 
-// (inside an open ncclGroupStart: a failing HIP call closes the group before it returns)
-#define HIP_TRY_IN_GROUP(expr)                                                                   \
-    do {                                                                                         \
-        const hipError_t h_ = (expr);                                                            \
-        if (h_ != hipSuccess) {                                                                  \
-            if (in_group) (void)api.GroupEnd();                                                  \
-            return fail(CHUNKY_E_HIP, "%s: %s", #expr, hipGetErrorString(h_));                  \
-        }                                                                                        \
-    } while (0)
+// (inside an open ncclGroupStart: the thread's group has to be closed whatever happened — what was queued up to there may be
+// a partial list, e.g. a Send whose Recv was never posted; the caller, group_gather, ABORTS the communicators before it waits
+// for any stream, which is what unblocks such a kernel)
 #define RCCL_TRY(expr)                                                                           \
     do {                                                                                         \
         const ncclResult_t e_ = (expr);                                                          \
@@ -1647,14 +1756,30 @@ static int group_gather_peer(chunky_render* r) {
         }                                                                                        \
     } while (0)
 
-// ONE grouped RCCL operation: member i's ncclSend of its packed blocks on its own stream (behind its queued passes and the
-// pack kernel), member 0's matching ncclRecv's on its stream (ahead of the scatter kernels).
+// Every member's stream drained of the passes queued on it (plain blocking waits: nothing of RCCL is on the streams yet), so
+// that the deadline of the exchange that follows measures the exchange and not a long render before it.
+static int group_drain_passes(chunky_render* r, std::vector<int>* devices, std::vector<hipStream_t>* streams) {
+    for (chunky_render* part : r->parts) {
+        HIP_TRY(hipSetDevice(part->ctx->device));
+        HIP_TRY(hipStreamSynchronize(part->ctx->stream));
+        devices->push_back(part->ctx->device);
+        streams->push_back(part->ctx->stream);
+    }
+    return CHUNKY_OK;
+}
+
+// ONE grouped RCCL operation: member i's ncclSend of its packed blocks on its own stream (behind the pack kernel), member 0's
+// matching ncclRecv's on its stream (ahead of the scatter kernels).  Every call that can fail for reasons of its own — buffer
+// allocation, the pack launches, selecting a device — happens BEFORE ncclGroupStart.
 static int group_gather_sendrecv(chunky_render* r) {
     const RcclApi& api = rccl_api();
     chunky_ctx* g = r->ctx;
     chunky_render* p0 = r->parts[0];
     const size_t n = r->parts.size(), first = g->self_exchange ? 0 : 1;
     bool in_group = false;
+    std::vector<int> devices;
+    std::vector<hipStream_t> streams;
+    if (int rc = group_drain_passes(r, &devices, &streams)) return rc;
     for (size_t i = first; i < n; i++) {
         chunky_render* pi = r->parts[i];
         std::lock_guard<std::recursive_mutex> gi(pi->ctx->mu);
@@ -1669,28 +1794,22 @@ static int group_gather_sendrecv(chunky_render* r) {
         chunky_render* pi = r->parts[i];
         const size_t count = (size_t)pi->shard.n_local * 3;
         if (count == 0) continue;
-        HIP_TRY_IN_GROUP(hipSetDevice(pi->ctx->device));
+        (void)hipSetDevice(pi->ctx->device);  // (selected successfully a moment ago, in group_drain_passes)
         RCCL_TRY(api.Send(r->gather_send[i].p, count, ncclFloat, 0, g->comms[i], pi->ctx->stream));
-        HIP_TRY_IN_GROUP(hipSetDevice(p0->ctx->device));
+        (void)hipSetDevice(p0->ctx->device);
         RCCL_TRY(api.Recv(r->gather_recv[i].p, count, ncclFloat, (int)i, g->comms[0], p0->ctx->stream));
     }
     in_group = false;
     RCCL_TRY(api.GroupEnd());
-    if (int rc = gather_scatter(r, first)) return rc;  // (waits for member 0's stream: the receives are complete)
-    for (size_t i = 1; i < n; i++) {
-        HIP_TRY(hipSetDevice(r->parts[i]->ctx->device));
-        HIP_TRY(hipStreamSynchronize(r->parts[i]->ctx->stream));
-    }
-    for (size_t i = 0; i < n; i++) {  // a failure the communicator noticed by itself (a dead link, a dead peer)
-        ncclResult_t async = ncclSuccess;
-        if (api.CommGetAsyncError(g->comms[i], &async) == ncclSuccess && async != ncclSuccess)
-            return fail(CHUNKY_E_HIP, "RCCL communicator of member %zu: %s", i, api.str(async));
-    }
-    return CHUNKY_OK;
+    if (int rc = group_wait(g, devices, streams)) return rc;  // the sends and the receives are complete, or the deadline has passed
+    return gather_scatter(r, first);
 }
 
-// The literal form: member 0 clears what it does not own (the blocks earlier read-backs left there), every member's
-// framebuffer is then zero outside its own blocks, and ONE ncclReduce(sum) onto member 0 assembles the image in place.
+// The literal form: every member clears what it does not own (after chunky_render_set_shard on a live render a member may still
+// hold pixels of its old share; member 0 holds the blocks earlier read-backs left there), every framebuffer is then zero outside
+// its member's own blocks, and ONE ncclReduce(sum) onto member 0 assembles the image in place.  (Pixels NO member owns — the
+// other ranks' when the group itself is one rank of an outer chunky_render_set_shard split — are zero afterwards; the other two
+// transports leave them as they were.)
 static int group_gather_reduce(chunky_render* r) {
     const RcclApi& api = rccl_api();
     chunky_ctx* g = r->ctx;
@@ -1698,34 +1817,29 @@ static int group_gather_reduce(chunky_render* r) {
     const size_t n = r->parts.size();
     const size_t count = (size_t)p0->width * p0->height * 3;
     bool in_group = false;
-    {
-        std::lock_guard<std::recursive_mutex> g0(p0->ctx->mu);
-        HIP_TRY(hipSetDevice(p0->ctx->device));
-        HIP_TRY(launch_clear_foreign(p0->shard, p0->width, p0->height, p0->fb, p0->ctx->stream));
+    std::vector<int> devices;
+    std::vector<hipStream_t> streams;
+    if (int rc = group_drain_passes(r, &devices, &streams)) return rc;
+    for (size_t i = 0; i < n; i++) {
+        chunky_render* pi = r->parts[i];
+        std::lock_guard<std::recursive_mutex> gi(pi->ctx->mu);
+        HIP_TRY(hipSetDevice(pi->ctx->device));
+        HIP_TRY(launch_clear_foreign(pi->shard, pi->width, pi->height, pi->fb, pi->ctx->stream));
     }
     RCCL_TRY(api.GroupStart());
     in_group = true;
     for (size_t i = 0; i < n; i++) {
         chunky_render* pi = r->parts[i];
-        HIP_TRY_IN_GROUP(hipSetDevice(pi->ctx->device));
+        (void)hipSetDevice(pi->ctx->device);
         RCCL_TRY(api.Reduce(pi->fb, pi->fb, count, ncclFloat, ncclSum, 0, g->comms[i], pi->ctx->stream));
     }
     in_group = false;
     RCCL_TRY(api.GroupEnd());
-    for (size_t i = 0; i < n; i++) {
-        HIP_TRY(hipSetDevice(r->parts[i]->ctx->device));
-        HIP_TRY(hipStreamSynchronize(r->parts[i]->ctx->stream));
-    }
-    for (size_t i = 0; i < n; i++) {
-        ncclResult_t async = ncclSuccess;
-        if (api.CommGetAsyncError(g->comms[i], &async) == ncclSuccess && async != ncclSuccess)
-            return fail(CHUNKY_E_HIP, "RCCL communicator of member %zu: %s", i, api.str(async));
-    }
+    if (int rc = group_wait(g, devices, streams)) return rc;
     HIP_TRY(hipSetDevice(p0->ctx->device));
     return CHUNKY_OK;
 }
 #undef RCCL_TRY
-#undef HIP_TRY_IN_GROUP
 
 static int group_gather(chunky_render* r) {
     chunky_ctx* g = r->ctx;
@@ -1735,13 +1849,15 @@ static int group_gather(chunky_render* r) {
         // An RCCL call failed: the render must not be lost with it.  The members' own blocks are intact (the exchange only
         // ever writes buffers of its own, and — the reduce — pixels of member 0's image that member 0 does not own), so the
         // same read-back runs again on peer copies, and so does every later one; chunky_group_transport says why.
+        // ABORT FIRST: if an RCCL kernel sits unfinished on a member's stream (a dead peer, or the partial list of a call that
+        // failed inside ncclGroupStart), only ncclCommAbort ends it — a stream wait before the abort would never return.
         const std::string why = tls_error;
+        group_close_rccl(g, true);
         for (chunky_render* part : r->parts) {
             (void)hipSetDevice(part->ctx->device);
             (void)hipStreamSynchronize(part->ctx->stream);
         }
         (void)hipGetLastError();
-        group_close_rccl(g, true);
         g->transport = CHUNKY_TRANSPORT_PEER_COPY;
         g->transport_detail = "peer copies: " + why;
     }

@@ -1,11 +1,26 @@
 // rccl_dyn.hpp — RCCL, bound at run time.  The read-back exchange of a multi-GPU group (capi.hip group_gather) is one grouped
 // RCCL operation over xGMI when the collective library is there; the library is NOT a link-time dependency of
 // libchunky_hip.so: a JVM (or a 1-GPU box) without librccl still loads this library and renders, and a process that already
-// holds an RCCL (PyTorch ships its own, same soname) gets that one instead of a second copy.  Only the types come from
-// <rccl/rccl.h>; every function is looked up with dlsym.
+// holds an RCCL (PyTorch ships its own, same soname) gets that one instead of a second copy.  Nothing of RCCL is needed to
+// BUILD this library either: the handful of types and enumerators the calls take are declared here (their values are ABI:
+// rccl.h / nccl.h have not changed them), every function is looked up with dlsym.  Where <rccl/rccl.h> is installed, defining
+// CHUNKY_CHECK_RCCL_HEADER makes the compiler compare the two (tests/test_cabi.py does).
 #pragma once
 #include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#if defined(CHUNKY_CHECK_RCCL_HEADER)
 #include <rccl/rccl.h>
+static_assert(ncclSuccess == 0 && ncclSystemError == 2 && ncclRemoteError == 6 && ncclFloat == 7 && ncclSum == 0, "RCCL's enumerators moved");
+static_assert(sizeof(ncclComm_t) == sizeof(void*) && sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclRedOp_t) == sizeof(int),
+              "RCCL's types changed size");
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5,
+               ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 #include <cstdlib>
 #include <mutex>

@@ -13,6 +13,7 @@ int default_wide_levels(int depth, int* level_bits) {
     // world is then two dependent reads per lookup instead of three (the reference's benchmark city: 5153 -> 5424 Msamples/s;
     // a depth-7 world as ONE 128^3 node measured 8 % slower than 4 + 3 and keeps its level)
     if (depth < 0) depth = 0;
+#ifdef CHUNKY_TUNING  // tuning builds only (tools/variants.sh): the shipping library reads no tuning variable
     if (const char* e = getenv("CHUNKY_WIDE_LEVELS")) {  // tuning runs: an explicit split "top,l1,l2,..." (runs the generic tree form)
         int b[kWideMaxLevels], n = 0, sum = 0;
         for (const char* p = e; *p && n < kWideMaxLevels;) {
@@ -28,14 +29,19 @@ int default_wide_levels(int depth, int* level_bits) {
             return n;
         }
     }
+#endif
     int most_top = 6;
+    bool fixed_top = false;
+#ifdef CHUNKY_TUNING
     if (const char* e = getenv("CHUNKY_WIDE_TOP_BITS")) {  // tuning runs: a larger dense top (7: 128^3 entries = 8 MiB) for one level less
         const int v = atoi(e);
         if (v >= 4 && v <= 7) most_top = v;
+        fixed_top = true;
     }
+#endif
     int n3 = depth <= most_top ? 0 : (depth - most_top + 2) / 3;
     if (n3 > kWideMaxLevels - 1) n3 = kWideMaxLevels - 1;
-    if (!getenv("CHUNKY_WIDE_TOP_BITS") && n3 >= 2 && depth - 3 * n3 == 4) n3 -= 1;
+    if (!fixed_top && n3 >= 2 && depth - 3 * n3 == 4) n3 -= 1;
     level_bits[0] = depth - 3 * n3;
     for (int i = 1; i <= n3; i++) level_bits[i] = 3;
     return n3 + 1;

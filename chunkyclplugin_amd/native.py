@@ -87,6 +87,24 @@ def build(force: bool = False, extra_flags=(), out: Optional[str] = None, objdir
     return out or LIB_PATH
 
 
+TUNING_LIB_PATH = os.path.join(PKG_DIR, "libchunky_hip_tuning.so")
+
+
+def build_tuning(force: bool = False) -> str:
+    """The same library compiled with -DCHUNKY_TUNING: the build that reads the tuning / test-rig environment variables
+    (CHUNKY_WIDE_LEVELS, CHUNKY_WIDE_TOP_BITS, CHUNKY_DEBUG_WIDE_BITS, CHUNKY_BVH_LAYOUT, CHUNKY_GROUP_TRANSPORT,
+    CHUNKY_GROUP_SELF_EXCHANGE, CHUNKY_GROUP_NO_PROBE, CHUNKY_GROUP_TIMEOUT_MS, CHUNKY_RCCL_TRY_SHARED).  The shipping
+    library reads none of them; tests and tools that need one run a child process with CHUNKY_HIP_LIB pointing here."""
+    stale = not os.path.exists(TUNING_LIB_PATH)
+    if not stale:
+        t = os.path.getmtime(TUNING_LIB_PATH)
+        deps = [p for p in (os.path.join(CSRC, f) for f in os.listdir(CSRC)) if os.path.isfile(p)] + [HEADER]
+        stale = any(os.path.getmtime(d) > t for d in deps)
+    if force or stale:
+        build(force=True, extra_flags=["-DCHUNKY_TUNING"], out=TUNING_LIB_PATH, objdir=os.path.join(CSRC, "build", "tuning"))
+    return TUNING_LIB_PATH
+
+
 def declared_symbols() -> List[str]:
     """Every function include/chunky_hip.h declares."""
     text = open(HEADER).read()

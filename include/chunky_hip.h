@@ -81,13 +81,21 @@ int chunky_group_peer_status(chunky_ctx* ctx, int* out, int n);
  *   CHUNKY_TRANSPORT_PEER_COPY      the packed blocks travel by hipMemcpyPeerAsync (chunky_group_peer_status says how):
  *                                   the fallback when RCCL cannot be bound, the communicator cannot be created (members
  *                                   sharing a device), or an RCCL call fails later — the render survives and `detail` says why.
- * All three leave the same bytes in member 0's image.  chunky_group_transport reports the transport the next read-back will
- * use and a human-readable detail (library file and version, or the reason for the fallback); chunky_group_set_transport
- * picks one (CHUNKY_E_STATE when it needs a communicator that does not exist).  The environment variable
- * CHUNKY_GROUP_TRANSPORT = peer | rccl | rccl-reduce sets the initial choice.  On a chunky_init context: PEER_COPY, nothing
- * to exchange.  (Two more variables exist for the test rigs that exercise this on ONE GPU, tests/test_gpu_rccl_transport.py:
- * CHUNKY_GROUP_SELF_EXCHANGE=1 sends member 0's own blocks through the exchange too, CHUNKY_RCCL_TRY_SHARED=1 hands a device
- * list with duplicates to ncclCommInitAll instead of skipping it.  Neither changes a result.) */
+ * All three leave the same bytes in the pixels the group's members own (with an outer chunky_render_set_shard split the REDUCE
+ * form also zeroes the pixels of member 0's image that no member owns; the other two leave them alone).
+ * First contact is checked, not assumed: before RCCL becomes a group's transport, chunky_group_create sends a known pattern from
+ * every member to member 0 through the new communicators and compares the bytes; an error, a wrong byte or an exchange that does
+ * not finish makes the group start on peer copies, with the reason in `detail`.  No exchange waits in the driver behind an RCCL
+ * kernel: the library polls the members' streams and the communicators' asynchronous errors, and after 30 s without completion
+ * (or on any RCCL error) it calls ncclCommAbort FIRST — the one call that ends a collective whose peer or link died — then drains
+ * the streams and repeats that read-back, and every later one, on peer copies.
+ * chunky_group_transport reports the transport the next read-back will use and a human-readable detail (library file and
+ * version, or the reason for the fallback); chunky_group_set_transport picks one (CHUNKY_E_STATE when it needs a communicator
+ * that does not exist).  On a chunky_init context: PEER_COPY, nothing to exchange.
+ * Environment: the shipping library reads ONE variable, CHUNKY_RCCL_LIB (a deployment's own librccl file).  Everything else —
+ * the initial transport, the one-GPU rigs of tests/test_gpu_rccl_transport.py (CHUNKY_GROUP_TRANSPORT, CHUNKY_GROUP_SELF_EXCHANGE,
+ * CHUNKY_GROUP_NO_PROBE, CHUNKY_GROUP_TIMEOUT_MS, CHUNKY_RCCL_TRY_SHARED) and the tuning overrides of the octree / BVH re-layouts —
+ * exists only in a build with -DCHUNKY_TUNING (chunkyclplugin_amd/native.py build_tuning), never in what a JVM loads. */
 #define CHUNKY_TRANSPORT_PEER_COPY 0
 #define CHUNKY_TRANSPORT_RCCL_SENDRECV 1
 #define CHUNKY_TRANSPORT_RCCL_REDUCE 2

@@ -58,3 +58,37 @@ def test_group_without_devices_fails_loudly():
     if L.chunky_device_count() == 0:
         assert L.chunky_group_create(two, 2, C.byref(h)) == native.E_NO_DEVICE and not h.value
         assert b"member 0" in L.chunky_last_error()
+
+
+RIG_VARIABLES = (b"CHUNKY_WIDE_LEVELS", b"CHUNKY_WIDE_TOP_BITS", b"CHUNKY_DEBUG_WIDE_BITS", b"CHUNKY_BVH_LAYOUT", b"CHUNKY_GROUP_TRANSPORT",
+                 b"CHUNKY_GROUP_SELF_EXCHANGE", b"CHUNKY_GROUP_NO_PROBE", b"CHUNKY_GROUP_TIMEOUT_MS", b"CHUNKY_RCCL_TRY_SHARED")
+
+
+def test_the_shipping_library_reads_no_tuning_variable():
+    """What a JVM loads must not be steerable through the environment: the names of the tuning / test-rig variables do not even
+    occur in libchunky_hip.so (the one variable it reads is CHUNKY_RCCL_LIB, a deployment's own librccl file); they exist in the
+    -DCHUNKY_TUNING build that rig tests load in child processes."""
+    native.build()
+    shipping = open(native.LIB_PATH, "rb").read()
+    for name in RIG_VARIABLES:
+        assert name not in shipping, name
+    assert b"CHUNKY_RCCL_LIB" in shipping
+    tuning = open(native.build_tuning(), "rb").read()
+    for name in RIG_VARIABLES:
+        assert name in tuning, name
+
+
+def test_rccl_is_not_needed_to_build_the_library_and_the_local_declarations_match_it(tmp_path):
+    """csrc/rccl_dyn.hpp declares the few RCCL types and enumerators itself (the functions come from dlsym): no RCCL header is
+    included by a normal build.  Where <rccl/rccl.h> is installed the compiler compares the two."""
+    import os
+    import subprocess
+    text = open(os.path.join(native.CSRC, "rccl_dyn.hpp")).read()
+    assert "#if defined(CHUNKY_CHECK_RCCL_HEADER)\n#include <rccl/rccl.h>" in text and text.count("#include <rccl/rccl.h>") == 1
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no RCCL header on this box")
+    src = tmp_path / "check.cpp"
+    src.write_text('#include "rccl_dyn.hpp"\nint main() { return chunky::rccl_api().usable() ? 0 : 0; }\n')
+    p = subprocess.run(["hipcc", "-x", "hip", "--offload-host-only", "-std=c++17", "-DCHUNKY_CHECK_RCCL_HEADER", "-I" + native.CSRC, "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]

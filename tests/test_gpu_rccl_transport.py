@@ -23,8 +23,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def child(devices, scene="outdoor", then=None, **env):
     e = dict(os.environ)
-    for k in ("CHUNKY_RCCL_LIB", "CHUNKY_GROUP_TRANSPORT", "CHUNKY_GROUP_SELF_EXCHANGE", "CHUNKY_RCCL_TRY_SHARED", "RCCL_STUB_MODE"):
+    for k in ("CHUNKY_RCCL_LIB", "CHUNKY_GROUP_TRANSPORT", "CHUNKY_GROUP_SELF_EXCHANGE", "CHUNKY_RCCL_TRY_SHARED", "RCCL_STUB_MODE",
+              "CHUNKY_GROUP_NO_PROBE", "CHUNKY_GROUP_TIMEOUT_MS", "CHUNKY_HIP_LIB"):
         e.pop(k, None)
+    if not env.pop("shipping", False):
+        # the rig variables exist in the -DCHUNKY_TUNING build only (native.build_tuning): the shipping library reads none of them
+        e["CHUNKY_HIP_LIB"] = native.build_tuning()
     e.update({k: str(v) for k, v in env.items()})
     cmd = [sys.executable, os.path.join(HERE, "rccl_child.py"), devices, scene] + ([str(then)] if then is not None else [])
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
@@ -86,12 +90,45 @@ def test_rccl_that_does_not_load(stub):
     assert out["identical"] and out["identical_again"]
 
 
+@pytest.mark.parametrize("mode", ["fail_send", "fail_end", "async", "ok"])
+def test_first_contact_probe_catches_a_broken_rccl_at_group_creation(stub, mode):
+    """chunky_group_create sends a known pattern from every member to member 0 through the new communicators and compares the
+    bytes: an RCCL that returns an error, reports one asynchronously, or — mode "ok" — claims success and moves nothing never
+    becomes the group's transport.  The reason is in chunky_group_transport, the render runs on peer copies."""
+    out = child("0,0,0", CHUNKY_RCCL_LIB=stub["full"], CHUNKY_RCCL_TRY_SHARED=1, RCCL_STUB_MODE=mode)
+    assert out["before"]["name"] == "peer-copy" and "failed its first exchange" in out["before"]["detail"], out
+    assert ("stub" in out["before"]["detail"]) if mode != "ok" else ("arrived as 0" in out["before"]["detail"]), out
+    assert out["identical"] and out["identical_again"] and out["first_nonzero"]
+
+
+def test_real_rccl_passes_the_probe_in_the_shipping_library():
+    """The library as shipped (no rig variable is read): a one-member group owns a real communicator, its first exchange —
+    a send to itself — is verified, and RCCL is the transport."""
+    out = child("0", "outdoor", shipping=True)
+    assert out["before"]["name"] == "rccl-sendrecv" and "first exchange verified" in out["before"]["detail"], out
+    assert out["identical"] and out["identical_again"]
+    # ... and the rig variables mean nothing to it: asking for the reduce through the environment changes nothing
+    out = child("0", "outdoor", shipping=True, CHUNKY_GROUP_TRANSPORT="rccl-reduce")
+    assert out["before"]["name"] == "rccl-sendrecv", out
+
+
+@pytest.mark.parametrize("transport", ["rccl", "rccl-reduce"])
+def test_an_exchange_that_never_finishes_is_aborted_not_waited_for(transport):
+    """A deadline of 0 ms makes the REAL RCCL's exchange "hang": the library must not sit in hipStreamSynchronize behind the
+    collective's kernel — it polls, gives up, calls ncclCommAbort FIRST (the one call that ends a stuck RCCL kernel), then drains
+    the streams and repeats the read-back on peer copies.  The image is the reference's."""
+    out = child("0", "outdoor", CHUNKY_GROUP_SELF_EXCHANGE=1, CHUNKY_GROUP_NO_PROBE=1, CHUNKY_GROUP_TIMEOUT_MS=0, CHUNKY_GROUP_TRANSPORT=transport)
+    assert out["before"]["backend"] == "rccl", out
+    assert out["after_first"]["name"] == "peer-copy" and "unfinished after 0 ms" in out["after_first"]["detail"], out
+    assert out["identical"] and out["identical_again"] and out["first_nonzero"]
+
+
 @pytest.mark.parametrize("mode,transport", [("fail_send", "rccl"), ("fail_end", "rccl"), ("async", "rccl"),
                                             ("fail_send", "rccl-reduce"), ("fail_end", "rccl-reduce"), ("async", "rccl-reduce")])
 def test_rccl_that_breaks_after_the_communicator_exists(stub, mode, transport):
-    """The communicator was created (the stand-in accepts anything), then the first exchange fails: that read-back and every later
-    one run on peer copies, nothing of the render is lost."""
-    out = child("0,0,0", CHUNKY_RCCL_LIB=stub["full"], CHUNKY_RCCL_TRY_SHARED=1, RCCL_STUB_MODE=mode, CHUNKY_GROUP_TRANSPORT=transport)
+    """The communicator was created (the stand-in accepts anything; the first-contact probe is switched off here), then the first
+    exchange fails: that read-back and every later one run on peer copies, nothing of the render is lost."""
+    out = child("0,0,0", CHUNKY_RCCL_LIB=stub["full"], CHUNKY_RCCL_TRY_SHARED=1, RCCL_STUB_MODE=mode, CHUNKY_GROUP_TRANSPORT=transport, CHUNKY_GROUP_NO_PROBE=1)
     assert out["before"]["backend"] == "rccl" and "3 rank(s)" in out["before"]["detail"], out
     assert out["after_first"]["name"] == "peer-copy" and "stub" in out["after_first"]["detail"], out
     assert out["identical"] and out["identical_again"] and out["first_nonzero"]

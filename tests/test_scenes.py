@@ -164,3 +164,43 @@ def test_benchmark_fixture_is_what_the_loader_makes_of_the_reference_files():
         np.testing.assert_array_equal(np.asarray(getattr(made, f)), np.asarray(getattr(kept, f)), err_msg=f)
     kinds = kept.block_palette.reshape(-1, 2)[:, 0]
     assert (kinds == 2).sum() > 1000 and (kinds == 3).sum() >= 20 and (kinds == 1).sum() > 1500   # model blocks are part of the city now
+
+
+def test_slab_octree_builder_equals_the_dense_builder():
+    """build_octree_slab (the beyond-cache world of bench.py --config 5 is 2048 x 256 x 2048: its dense cube would be 34 GB) packs
+    a slab exactly as build_octree packs the same world padded with air: same merging, same breadth-first numbering."""
+    rng = np.random.default_rng(3)
+    n, h, depth = 64, 16, 6
+    t = np.zeros((n, h, n), np.int16)
+    hm = (rng.random((n, n)) * 12).astype(int)
+    for x in range(n):
+        for z in range(n):
+            t[x, :hm[x, z] + 1, z] = 1 + (x * 7 + z) % 3
+    t[5:9, 2:4, 5:9] = 255
+    t[16:32, 0:16, 32:48] = 2          # a whole 16^3 cell: merges one level above the slab's thickness
+    dense = np.zeros((n, n, n), np.int32)
+    dense[:, :h, :] = t
+    dense[dense == 255] = scenes.ANY_TYPE
+    np.testing.assert_array_equal(scenes.build_octree_slab(t, depth, 255), scenes.build_octree(dense, depth, "bfs"))
+    # a slab as thick as the world is wide, and an all-air world
+    cube = (rng.random((8, 8, 8)) < 0.3).astype(np.int16)
+    np.testing.assert_array_equal(scenes.build_octree_slab(cube, 3, 255), scenes.build_octree(cube.astype(np.int32), 3, "bfs"))
+    assert list(scenes.build_octree_slab(np.zeros((8, 2, 8), np.int16), 3, 255)) == [0]
+
+
+def test_big_world_generator_small():
+    """big_outdoor_world at 16 x 16 chunks: the outdoor world's palettes, a depth-8 octree whose wide re-layout answers every sampled
+    cell as the reference walk does."""
+    from chunkyclplugin_amd import native
+    sc = scenes.big_outdoor_world(chunks=16, width=64, img_height=48)
+    small = scenes.outdoor_world(chunks=1, height=16, width=64, img_height=48)
+    assert sc.octree_depth == 8 and np.array_equal(sc.block_palette, small.block_palette) and np.array_equal(sc.atlas, small.atlas)
+    rng = np.random.default_rng(5)
+    xyz = rng.integers(0, 256, size=(4000, 3)).astype(np.int32)
+    data, level, _n = native.widetree_lookup(sc.octree, sc.octree_depth, xyz)
+    for (x, y, z), d, l in zip(xyz[:600], data[:600], level[:600]):
+        lv, v = sc.octree_depth, int(sc.octree[0])
+        while v > 0:
+            lv -= 1
+            v = int(sc.octree[v + ((((x >> lv) & 1) << 2) | (((y >> lv) & 1) << 1) | ((z >> lv) & 1))])
+        assert (-v, lv) == (int(d), int(l))

@@ -10,7 +10,7 @@ for v in $variants; do
   unset CHUNKY_HIP_LIB; envset=""
   case "$v" in
     default) ;;
-    ENV:*) envset="${v#ENV:}"; export "$envset" ;;
+    ENV:*) envset="${v#ENV:}"; export "$envset"; export CHUNKY_HIP_LIB=$PWD/chunkyclplugin_amd/libchunky_hip_tuning.so ;;  # (tuning variables are read by the -DCHUNKY_TUNING build only)
     *) export CHUNKY_HIP_LIB=$PWD/.variants/libchunky_hip_$v.so ;;
   esac
   for w in $what; do

@@ -10,6 +10,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the fuzz moves the BVH records about (CHUNKY_BVH_LAYOUT) and sends a one-member group's own blocks through RCCL (CHUNKY_GROUP_SELF_EXCHANGE):
+# rig variables of the -DCHUNKY_TUNING build only, which is what it therefore loads (set before the binding is imported)
+if "CHUNKY_HIP_LIB" not in os.environ:
+    os.environ["CHUNKY_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "chunkyclplugin_amd", "libchunky_hip_tuning.so")
 from chunkyclplugin_amd import native, parallel, scenes  # noqa: E402
 from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, RendererInstance  # noqa: E402
 from oracle import binding  # noqa: E402
