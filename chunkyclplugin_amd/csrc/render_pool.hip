@@ -744,6 +744,12 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
             if (tree != 17) tree = -1;
             park = 16;
             k = tree == 17 ? render_pool<17, 16, true, true> : render_pool<-1, 16, true, true>;
+#ifdef CHUNKY_POOL_BVH_PARK  // tuning builds (tools/variants.sh): a fixed pool size for the entity kernel, e.g. 8 parked paths at six waves
+        } else if (true) {
+            if (tree != 17) tree = -1;
+            park = CHUNKY_POOL_BVH_PARK;
+            k = tree == 17 ? render_pool<17, CHUNKY_POOL_BVH_PARK, false, true> : render_pool<-1, CHUNKY_POOL_BVH_PARK, false, true>;
+#endif
         } else if (park == 32) {
             k = tree == 17 ? render_pool<17, 32, false, true> : (tree == 18 ? render_pool<18, 32, false, true> : render_pool<-1, 32, false, true>);
         } else {
