@@ -98,7 +98,8 @@ struct DevBuf {
 struct chunky_scene {
     chunky_ctx* ctx = nullptr;
     DevBuf octree, blocks, materials, aabbs, quads, trigs, world_bvh, actor_bvh, atlas, sky, wide, block_info, quad_aux;
-    DevBuf mat8, aabb_rec, quad_rec;                   // 16-byte-aligned re-layouts of the palettes (rt_device.hpp)
+    DevBuf mat8;                                       // 16-byte-aligned re-layouts of the palettes: materials, boxes, quads (rt_device.hpp)
+    bool models_on_records = false;                    // every model block has its records in mat8 (derive_records)
     DevBuf bvh_rec;                                    // both entity BVHs as 64-byte inner nodes, then their triangles as 80-byte records
     size_t tri_off = 0;                                // byte offset of the first triangle record in bvh_rec
     DevBuf emitters;                                   // emitter next-event estimation: {x, y, z, level << 25 | block} per emitter leaf
@@ -108,7 +109,7 @@ struct chunky_scene {
     int world_root = 0, actor_root = 0;                // first reference of each BVH in bvh_rec / tri_rec (rt_device.hpp)
     bool bvh_dirty = false;
     std::vector<int32_t> host_blocks, host_materials, host_aabbs, host_quads;  // kept to rebuild what is derived from them
-    bool derived_dirty = false;                        // block_info, quad_aux, mat8, aabb_rec, quad_rec
+    bool derived_dirty = false;                        // block_info, quad_aux, mat8
     WideTree wide_meta;  // host copy kept so the kind bits can follow the block palette; nlev == 0 when absent
     bool wide_dirty = false;
     int octree_depth = -1;
@@ -715,34 +716,49 @@ static bool build_quad_aux(const std::vector<int32_t>& B, const std::vector<int3
 }
 
 // Everything the kernels read that is derived from the four palettes (rt_device.hpp has the layouts):
-//   block_info  per block {type, pointer, 5 material words of a full cube, model record}
-//   mat8        materials at a 32-byte stride (two 16-byte reads instead of five unaligned dwords)
-//   aabb_rec    AABB-model boxes as three 16-byte words each, materials as mat8 indices
-//   quad_rec    quad-model quads as six 16-byte words each (the material's five words inline), with the ray-independent values of K/primitives.h:262-276
-//               (unit normal, its dot with the origin, |xv|^2, |yv|^2) evaluated here with the kernel's own rt_math.h
+//   block_info  per block {type, pointer, 5 material words of a full cube, model record}; of a full cube the pointer's place holds
+//               the material's emittance as a float — (word 4 & 0xFF) / 255.0, the double site K/material.h:79 — so that no
+//               kernel looks it up
+//   records     ONE array of 16-byte words (SceneView::mat8), everything in it addressed by word index:
+//               materials from word 0 at a 32-byte stride {flags, tint, textureSize, color} {normal_emittance, word 5, emittance float, 0},
+//               then the AABB-model boxes (three words each, materials as word indices) and the quad-model quads (five words each,
+//               with the ray-independent values of K/primitives.h:262-276 — unit normal, its dot with the origin, |xv|^2, |yv|^2 —
+//               evaluated here with the kernel's own rt_math.h, material as a word index)
 // A block whose model cannot be re-laid out (pointer outside its palette, more than 255 primitives, a material pointer
-// that is not a whole material) keeps model record 0 and takes the path that reads the packed palettes as they are.
+// that is not a whole material) keeps model record 0 and takes the path that reads the packed palettes as they are —
+// `all_on_records` then is false and the scene renders on the kernels that have that path (render_pool's BLOCK phase reads
+// records only).
 // The host half of rebuild_derived: everything it derives from the four palettes, as plain vectors (no device call: this is the part
 // that reads caller-supplied ints, and tests/sanitize/capi_host_fuzz.cpp runs it under AddressSanitizer on hostile palettes).
 struct DerivedRecords {
-    std::vector<int32_t> info, mat8, aabb_rec, quad_rec;
+    std::vector<int32_t> info, mat8, prims;  // prims: boxes and quads, uploaded behind mat8 (word index = mat8 words + offset)
+    bool all_on_records = true;
 };
+static int32_t emittance_float_bits(int32_t normal_emittance) {
+    const float f = (float)((double)(normal_emittance & 0xFF) / 255.0);  // K/material.h:79: evaluated in double, stored as float
+    int32_t i;
+    memcpy(&i, &f, 4);
+    return i;
+}
 static void derive_records(const std::vector<int32_t>& B, const std::vector<int32_t>& M, const std::vector<int32_t>& A, const std::vector<int32_t>& Q,
                            DerivedRecords* out) {
     const size_t n_blocks = B.size() / 2, n_mats = M.size() / 6;
-    std::vector<int32_t>&mat8 = out->mat8, &info = out->info, &aabb_rec = out->aabb_rec, &quad_rec = out->quad_rec;
+    std::vector<int32_t>&mat8 = out->mat8, &info = out->info, &prims = out->prims;
+    out->all_on_records = true;
     mat8.assign(n_mats * 8, 0);
-    for (size_t m = 0; m < n_mats; m++)
+    for (size_t m = 0; m < n_mats; m++) {
         for (int w = 0; w < 6; w++) mat8[m * 8 + w] = M[m * 6 + w];  // word 5 (spec | metal | rough) rides in the second word
-    auto mat_index = [&](int32_t ptr, int32_t* out) {  // packed material pointer -> index of its first 16-byte word in mat8
+        mat8[m * 8 + 6] = emittance_float_bits(M[m * 6 + 4]);
+    }
+    auto mat_index = [&](int32_t ptr, int32_t* out) {  // packed material pointer -> index of its first 16-byte word
         if (ptr < 0 || ptr % 6 != 0 || (size_t)ptr / 6 >= n_mats) return false;
         *out = (ptr / 6) * 2;
         return true;
     };
+    const int64_t prim_base = (int64_t)n_mats * 2;  // first word of `prims` in the uploaded array
     info.assign(n_blocks * 8, 0);
-    aabb_rec.clear();
-    quad_rec.clear();
-    std::vector<int64_t> aabb_at(A.size(), -1), quad_at(Q.size(), -1);  // model pointer -> first record (models are shared between blocks)
+    prims.clear();
+    std::vector<int64_t> aabb_at(A.size(), -1), quad_at(Q.size(), -1);  // model pointer -> first word (models are shared between blocks)
     for (size_t k = 0; k < n_blocks; k++) {
         int32_t* e = &info[k * 8];
         const int32_t type = B[2 * k], ptr = B[2 * k + 1];
@@ -752,6 +768,7 @@ static void derive_records(const std::vector<int32_t>& B, const std::vector<int3
             if (ptr >= 0 && (size_t)ptr + 5 <= M.size()) {
                 for (int w = 0; w < 5; w++) e[2 + w] = M[(size_t)ptr + w];
                 if ((size_t)ptr + 6 <= M.size()) e[7] = M[(size_t)ptr + 5];  // material word 5 (extensions)
+                e[1] = emittance_float_bits(M[(size_t)ptr + 4]);
             } else {
                 e[0] = 0x7FFFFFFF;  // malformed cube: an unknown model type never hits (K/block.h:44-47)
             }
@@ -773,14 +790,18 @@ static void derive_records(const std::vector<int32_t>& B, const std::vector<int3
                         sound = prim[13] >= 0 && (size_t)prim[13] + 6 <= M.size();
                     }
                 }
+                if (sound && count == 0) e[0] = 0x7FFFFFFF;  // a model without primitives never hits and writes nothing (K/primitives.h:165-319)
             }
             if (!sound) e[0] = 0x7FFFFFFF;
         }
         if (e[0] == 2) {
             const int64_t count = A[(size_t)ptr];
-            if (count < 1 || count > 255) continue;
+            if (count > 255) {
+                out->all_on_records = false;
+                continue;
+            }
             if (aabb_at[(size_t)ptr] < 0) {
-                const int64_t first = (int64_t)aabb_rec.size() / 12;
+                const int64_t first = prim_base + (int64_t)prims.size() / 4;
                 bool ok = true;
                 std::vector<int32_t> rec((size_t)count * 12);
                 for (int64_t i = 0; i < count && ok; i++) {
@@ -793,17 +814,21 @@ static void derive_records(const std::vector<int32_t>& B, const std::vector<int3
                     aabb_at[(size_t)ptr] = -2;
                 } else {
                     aabb_at[(size_t)ptr] = first;
-                    aabb_rec.insert(aabb_rec.end(), rec.begin(), rec.end());
+                    prims.insert(prims.end(), rec.begin(), rec.end());
                 }
             }
-            if (aabb_at[(size_t)ptr] >= 0 && aabb_at[(size_t)ptr] < (1 << 22)) e[7] = (int32_t)((aabb_at[(size_t)ptr] << 8) | count);
+            if (aabb_at[(size_t)ptr] >= 0 && aabb_at[(size_t)ptr] + 3 * count < (1 << 24)) e[7] = (int32_t)((aabb_at[(size_t)ptr] << 8) | count);
+            if (e[7] == 0) out->all_on_records = false;
         } else if (e[0] == 3) {
             const int64_t count = Q[(size_t)ptr];
-            if (count < 1 || count > 255) continue;
+            if (count > 255) {
+                out->all_on_records = false;
+                continue;
+            }
             if (quad_at[(size_t)ptr] < 0) {
-                const int64_t first = (int64_t)quad_rec.size() / 24;
+                const int64_t first = prim_base + (int64_t)prims.size() / 4;
                 bool ok = true;
-                std::vector<int32_t> rec((size_t)count * 24);
+                std::vector<int32_t> rec((size_t)count * 20);
                 for (int64_t i = 0; i < count && ok; i++) {
                     const int32_t* q = &Q[(size_t)(ptr + 1 + 15 * i)];
                     float f[9];
@@ -816,29 +841,23 @@ static void derive_records(const std::vector<int32_t>& B, const std::vector<int3
                                           rt_dot3(f[6], f[7], f[8], f[6], f[7], f[8])};
                     int32_t a[6];
                     memcpy(a, aux, sizeof a);
-                    int32_t* r = &rec[(size_t)i * 24];
+                    int32_t* r = &rec[(size_t)i * 20];
                     r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = a[3];      // origin, dot(n, origin)
                     r[4] = q[3]; r[5] = q[4]; r[6] = q[5]; r[7] = a[4];      // xv, |xv|^2
                     r[8] = q[6]; r[9] = q[7]; r[10] = q[8]; r[11] = a[5];    // yv, |yv|^2
-                    r[12] = q[9]; r[13] = q[10]; r[14] = q[11]; r[15] = q[12];  // uv
-                    r[16] = a[0]; r[17] = a[1]; r[18] = a[2];                // unit normal
-                    int32_t m8 = 0;
-                    ok = mat_index(q[13], &m8);                              // the quad's material, inline: one dependent read less
-                    if (ok && (M[(size_t)q[13]] & 2)) ok = false;          // an emittance texture needs the full word: packed path
-                    if (ok) {
-                        const int32_t* m = &M[(size_t)q[13]];
-                        r[19] = (m[4] & 0xFF) | (int32_t)((uint32_t)m[5] << 8);
-                        r[20] = m[0]; r[21] = m[1]; r[22] = m[2]; r[23] = m[3];
-                    }
+                    r[12] = a[0]; r[13] = a[1]; r[14] = a[2];                // unit normal
+                    ok = mat_index(q[13], &r[15]);                           // the quad's material
+                    r[16] = q[9]; r[17] = q[10]; r[18] = q[11]; r[19] = q[12];  // uv
                 }
                 if (!ok) {
                     quad_at[(size_t)ptr] = -2;
                 } else {
                     quad_at[(size_t)ptr] = first;
-                    quad_rec.insert(quad_rec.end(), rec.begin(), rec.end());
+                    prims.insert(prims.end(), rec.begin(), rec.end());
                 }
             }
-            if (quad_at[(size_t)ptr] >= 0 && quad_at[(size_t)ptr] < (1 << 22)) e[7] = (int32_t)((quad_at[(size_t)ptr] << 8) | count);
+            if (quad_at[(size_t)ptr] >= 0 && quad_at[(size_t)ptr] + 5 * count < (1 << 24)) e[7] = (int32_t)((quad_at[(size_t)ptr] << 8) | count);
+            if (e[7] == 0) out->all_on_records = false;
         }
     }
 }
@@ -850,16 +869,18 @@ static int rebuild_derived(chunky_scene* s) {
     s->block_info.release();
     s->quad_aux.release();
     s->mat8.release();
-    s->aabb_rec.release();
-    s->quad_rec.release();
+    s->models_on_records = false;
     s->derived_dirty = false;
     if (B.empty() || M.empty()) return CHUNKY_OK;
     DerivedRecords d;
     derive_records(B, M, A, Q, &d);
     HIP_TRY(s->block_info.upload(d.info.data(), d.info.size() * 4, st));
+    // materials, boxes and quads as ONE array (every record a word index off one base), padded by two words: a staged fetch may
+    // read the two words behind a box
+    d.mat8.insert(d.mat8.end(), d.prims.begin(), d.prims.end());
+    d.mat8.resize(d.mat8.size() + 8, 0);
     HIP_TRY(s->mat8.upload(d.mat8.data(), d.mat8.size() * 4, st));
-    if (!d.aabb_rec.empty()) HIP_TRY(s->aabb_rec.upload(d.aabb_rec.data(), d.aabb_rec.size() * 4, st));
-    if (!d.quad_rec.empty()) HIP_TRY(s->quad_rec.upload(d.quad_rec.data(), d.quad_rec.size() * 4, st));
+    s->models_on_records = d.all_on_records;
     std::vector<float> aux;  // for quads that kept the packed path
     if (build_quad_aux(B, Q, &aux)) HIP_TRY(s->quad_aux.upload(aux.data(), aux.size() * 4, st));
     return CHUNKY_OK;
@@ -1202,8 +1223,7 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     v->bvh_stack_entries = (s->world_height > s->actor_height ? s->world_height : s->actor_height) + 1;
     v->block_info = (const int4*)s->block_info.p;
     v->mat8 = (const int4*)s->mat8.p;
-    v->aabb_rec = (const int4*)s->aabb_rec.p;
-    v->quad_rec = (const int4*)s->quad_rec.p;
+    v->models_on_records = (s->block_info.p && s->mat8.p && s->models_on_records) ? 1 : 0;
     v->wide = s->wide_meta.nlev > 0 ? (const uint32_t*)s->wide.p : nullptr;
     v->wide_nlev = s->wide_meta.nlev;
     for (int i = 0; i < 6; i++) {

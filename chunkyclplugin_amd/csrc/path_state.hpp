@@ -450,6 +450,157 @@ DEV int block_phase(const SceneView& S, LaneState& L) {
     leaf_exit<TREE, FARREG>(S, L, po, bx, by, bz, L.cand_level);
     return ST_MARCH;
 }
+
+// Everything listed is "used" here: the compiler can neither narrow nor split the loads that produce it nor move them past
+// this point, so a group of loads written one after the other is issued whole and back to back, and the ONE wait for all of
+// them sits at the first touch that follows.
+DEV void touch(int4& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+DEV void touch(uint32_t& a) { asm volatile("" : "+v"(a)); }
+
+// BLOCK as ONE staged machine (render_pool): the test of K/block.h:30-118 for every lane of the execution — full cubes, AABB
+// models, quad models — advancing together, one primitive per round, with every lane's reads of a stage issued before the wave
+// waits once:
+//   stage 0   the block's record (2 words)                                        — all lanes
+//   stage A   the primitive's geometry (5 words off the record base)               — model lanes; cubes test the unit box meanwhile
+//   stage C   the material the entry face / the quad points at (2 words)           — model lanes whose primitive passed; a cube's
+//                                                                                     material words came with stage 0
+//   stage D   the texel                                                            — every lane whose primitive passed
+//   (stage E  the emittance texel of a material with an emittance map: rare, its own branch)
+// A round costs three round trips to memory whatever the lanes hold, where the loop-per-model form (block_hit) runs the cube
+// test, the box loop and the quad loop one after the other with up to five dependent waits per primitive.  Per path the
+// operations and their order are block_hit's: the primitives of a model in palette order, each against the nearest accepted
+// so far, the record written by the accepted ones only (a cube's normal before its material test, K/block.h:59-60).
+// Needs S.models_on_records (capi.hip derive_records): every model block has its records; launch_pool checks.
+#ifndef CHUNKY_BLOCK_FORM
+#define CHUNKY_BLOCK_FORM 2  // tuning builds (tools/variants.sh): 0 = block_hit's loops, 2 = one staged machine, 3 = cubes first, then the models staged
+#endif
+template <int TREE, int END, bool FARREG = true>
+DEV int block_phase_staged(const SceneView& S, LaneState& L) {
+#if CHUNKY_BLOCK_FORM == 0
+    return block_phase<TREE, END, FARREG>(S, L);
+#else
+    const f3 pos = L.o + L.d * L.dist_march;
+    const f3 po = pos + L.d * kOffset;
+    const int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
+    const f3 no = (pos - L.d * kOffset) - mk3((float)bx, (float)by, (float)bz);
+    const bool main_ray = !L.shadow;  // a shadow ray needs the decision only: its record is a copy that is dropped (K/rayTracer.cl:101-106)
+    const int4* __restrict__ W = S.mat8;
+    const int4* __restrict__ rec = S.block_info + (unsigned)L.cand_data;
+    int4 a = rec[0], b = rec[1];
+    touch(a);
+    touch(b);
+    const int type = a.x;
+    const bool cube = type == 1, boxes = type == 2;
+    const bool model = (type == 2 || type == 3) && b.w != 0;
+    float best = rt_inf();
+    bool hit = false;
+#if CHUNKY_BLOCK_FORM == 3
+    if (cube) {  // K/block.h:48-65 with K/primitives.h:66-112; the UV point is no + tmin * pos (K/block.h:52)
+        const Slabs sl = slabs(0, 1, 0, 1, 0, 1, no, L.inv);
+        const float tn = slab_near(sl), tf = slab_far(sl);
+        if (!(tf < tn)) {
+            const Face f = face_unit(sl, tn, no + pos * tn);
+            if (main_ray) L.h.normal = f.n;  // written before the material test (K/block.h:59-60)
+            const unsigned flags = (unsigned)a.z;
+            f4 col;
+            if (material_color(flags, (unsigned)a.w, (unsigned)b.y, (flags & 4u) ? atlas_texel(S, f.u, f.v, b.y, b.x) : 0u, col)) {
+                float em = as_float(a.y);
+                if (flags & 2u) em = unpack_unorm8(atlas_texel(S, f.u, f.v, b.z, b.x)).w;
+                if (main_ray) {
+                    L.h.color = col;
+                    L.h.emittance = em;
+                    L.h.spec = b.w;
+                }
+                best = tn - kOffset;
+                hit = true;
+            }
+        }
+    }
+    const int n = model ? (b.w & 0xFF) : 0;  // any other type never hits (K/block.h:44-47)
+    int4 m0, m1;
+#else
+    const int n = cube ? 1 : (model ? (b.w & 0xFF) : 0);
+    int4 m0 = make_int4(a.z, a.w, b.x, b.y), m1 = make_int4(b.z, b.w, a.y, 0);  // the material in hand: a cube's came with its block record
+#endif
+    unsigned at = (unsigned)b.w >> 8;  // first word of the model's next primitive
+    for (int i = 0; i < n; i++) {
+        PrimCandidate c;
+        bool pass;
+#if CHUNKY_BLOCK_FORM != 3
+        if (cube) {
+            const Slabs sl = slabs(0, 1, 0, 1, 0, 1, no, L.inv);
+            const float tn = slab_near(sl), tf = slab_far(sl);
+            pass = !(tf < tn);
+            if (pass) {
+                const Face f = face_unit(sl, tn, no + pos * tn);
+                c = PrimCandidate{tn - kOffset, f.n, f.u, f.v, 0};
+                if (main_ray) L.h.normal = f.n;  // written before the material test (K/block.h:59-60)
+            }
+        } else
+#endif
+        {
+            const int4* __restrict__ g = W + at;
+            int4 g0 = g[0], g1 = g[1], g2 = g[2], g3, g4;
+            if (!boxes) {  // a quad is five words; the wait for everything this round fetched sits here or at the next touch
+                g3 = g[3];
+                g4 = g[4];
+                touch(g3);
+                touch(g4);
+            }
+            touch(g0);
+            touch(g1);
+            touch(g2);
+            if (boxes) {
+                pass = box_candidate(g0, g1, g2, no, L.d, L.inv, best, c);
+                at += 3u;
+            } else {
+                pass = quad_candidate(g0, g1, g2, g3, g4, no, L.d, best, c);
+                at += 5u;
+            }
+            if (pass) {
+                const int4* __restrict__ m = W + (unsigned)c.mat;
+                m0 = m[0];
+                m1 = m[1];
+            }
+        }
+        if (__ballot(pass) == 0) continue;  // (wave-uniform) nobody's primitive passed its geometry test
+        touch(m0);
+        touch(m1);
+        if (pass) {
+            const unsigned flags = (unsigned)m0.x;
+            uint32_t texel = 0u;
+            if (flags & 4u) texel = atlas_texel(S, c.u, c.v, m0.w, m0.z);
+            touch(texel);
+            f4 col;
+            if (material_color(flags, (unsigned)m0.y, (unsigned)m0.w, texel, col)) {
+                float em = as_float(m1.z);
+                if (flags & 2u) em = unpack_unorm8(atlas_texel(S, c.u, c.v, m1.x, m0.z)).w;
+                if (main_ray) {
+                    L.h.color = col;
+                    L.h.emittance = em;
+                    L.h.spec = m1.y;
+#if CHUNKY_BLOCK_FORM != 3
+                    if (!cube)
+#endif
+                        L.h.normal = c.n;
+                }
+                best = c.t;
+                hit = true;
+            }
+        }
+    }
+    if (hit) {
+        if (main_ray) {
+            L.h.distance = L.dist_march + best;
+            L.h.material = L.cand_data;
+        }
+        L.oct_hit = true;
+        return END;
+    }
+    leaf_exit<TREE, FARREG>(S, L, po, bx, by, bz, L.cand_level);
+    return ST_MARCH;
+#endif
+}
 struct WorkQueue {
     int* next;  // next unclaimed local pixel slot
 };

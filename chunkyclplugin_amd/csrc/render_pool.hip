@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         } else if (X == 1) {
             n_exec = count_lanes(st == ST_BLOCK);
             const SceneView S = arg_copy(&fresh_args()->S);
-            if (st == ST_BLOCK) st = block_phase<TREE, END, false>(S, L);
+            if (st == ST_BLOCK) st = block_phase_staged<TREE, END, false>(S, L);
         } else if (BVH && X == 5) {
             // The walk: inner-node visits and triangle tests are one step function (rwalk_step: the same four 16-byte reads
             // from one array or the other), so a walker is ST_BVH throughout and the loop below counts that one state.  The
@@ -799,7 +799,8 @@ bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, b
     // render_pool: always without entity BVHs; with them when they could be re-laid out (rt_device.hpp bvh_rec / tri_rec)
     // (its 7-word parked record counts march steps in 16 bits: a larger draw depth runs render_waves)
     const bool steps_fit = any_bvh || opts_extended(O) || O.draw_depth <= 65535;
-    return !(variant & 2) && !(variant & 8) && have_queue_and_staging && steps_fit &&
+    // (its BLOCK phase reads the model records only: a scene with a model block that could not be re-laid out takes the other kernels)
+    return !(variant & 2) && !(variant & 8) && have_queue_and_staging && steps_fit && S.block_info && S.models_on_records &&
            (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1)));
 }
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,

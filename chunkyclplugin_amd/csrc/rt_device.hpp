@@ -78,14 +78,15 @@ struct SceneView {
     // per quad, at the quad's own int offset in `quads`: {normal xyz, dot(normal, origin), |xv|^2, |yv|^2} — the
     // ray-independent part of K/primitives.h:262-276, evaluated once at upload with this same rt_math.h; null = compute
     const float* __restrict__ quad_aux;
-    // 16-byte-aligned re-layouts built at upload (capi.hip rebuild_derived); block_info word 7 of a model block =
-    // first record << 8 | primitive count, 0 = none (the packed palettes are read as they are):
-    //   mat8      per material two words {flags, tint, textureSize, color} {normal_emittance, word 5, 0, 0}
-    //   aabb_rec  per box three words {xmin, xmax, ymin, ymax} {zmin, zmax, flags, E} {S, W, T, B} (materials = mat8 indices)
-    //   quad_rec  per quad six words {o, dot(n, o)} {xv, |xv|^2} {yv, |yv|^2} {uv} {n, emittance byte | word 5 << 8} {flags, tint, textureSize, color}
+    // 16-byte-aligned re-layouts built at upload (capi.hip rebuild_derived), ONE allocation addressed in 16-byte words off
+    // `mat8` (every record is a 32-bit word index off one scalar base).  block_info word 7 of a model block = first word of
+    // its first primitive << 8 | primitive count, 0 = none (the packed palettes are read as they are); of a full cube word 1
+    // is the material's emittance as a float (the double site K/material.h:79 evaluated at upload):
+    //   materials  from word 0, two words each {flags, tint, textureSize, color} {normal_emittance, word 5, emittance float, 0}
+    //   AABB box   three words {xmin, xmax, ymin, ymax} {zmin, zmax, flags, E} {S, W, T, B} (materials = word indices)
+    //   quad       five words {o, dot(n, o)} {xv, |xv|^2} {yv, |yv|^2} {n, material (word index)} {uv}
     const int4* __restrict__ mat8;
-    const int4* __restrict__ aabb_rec;
-    const int4* __restrict__ quad_rec;
+    int models_on_records;  // every AABB / quad model block has its records (block_info word 7 != 0): render_pool's staged BLOCK needs that
     // Both entity BVHs re-laid out (capi.hip build_bvh_records), null when they could not be:
     //   bvh_rec  per inner node four words {ref A, ref B, 0, 0} {A: xmin, xmax, ymin, ymax} {A: zmin, zmax, B: xmin, xmax}
     //            {B: ymin, ymax, zmin, zmax} — A is the child that follows the node (K/bvh.h:73), B the one it points at
@@ -205,15 +206,18 @@ __device__ __constant__ const float kEmittanceLut[256] = {
 
 // K/material.h:31-82.  `shade` = false skips the writes that only matter to the main record
 // (shadow rays need the accept/reject decision only).
+// `em` = the value of the double site K/material.h:79 for this material, (ne & 0xFF) / 255.0 rounded to float: from the
+// table for the packed palettes, stored beside the material words in the records built at upload.
 DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsigned tex_size, unsigned color_w,
-                       unsigned ne, float u, float v, Hit& h, int m5 = 0);
+                       unsigned ne, float u, float v, Hit& h, int m5, float em);
 DEV bool material_sample(const SceneView& S, int material, float u, float v, Hit& h) {
     const int* m = S.materials + material;
-    return material_eval(S, m[0], m[1], m[2], m[3], m[4], u, v, h, m[5]);
+    const unsigned ne = m[4];
+    return material_eval(S, m[0], m[1], m[2], m[3], ne, u, v, h, m[5], kEmittanceLut[ne & 0xFF]);
 }
-DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsigned tex_size, unsigned color_w,
-                       unsigned ne, float u, float v, Hit& h, int m5) {
-    f4 c = (flags & 4) ? unpack_unorm8(atlas_texel(S, u, v, (int)color_w, (int)tex_size)) : color_from_argb(color_w);
+// The colour half of Material_sample (K/material.h:42-74) once the texel is there: false = transparent (nothing is written).
+DEV bool material_color(unsigned flags, unsigned tint, unsigned color_w, uint32_t texel, f4& c) {
+    c = (flags & 4) ? unpack_unorm8(texel) : color_from_argb(color_w);
     if (!(c.w > kEps)) return false;
     unsigned tt = tint >> 24;
     if (tt == 0xFF || tt == 1 || tt == 2 || tt == 3) {
@@ -221,11 +225,17 @@ DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsign
         f4 t = color_from_argb(tc);
         c = f4{c.x * t.x, c.y * t.y, c.z * t.z, c.w * t.w};
     }
+    return true;
+}
+DEV bool material_eval(const SceneView& S, unsigned flags, unsigned tint, unsigned tex_size, unsigned color_w,
+                       unsigned ne, float u, float v, Hit& h, int m5, float em) {
+    f4 c;
+    if (!material_color(flags, tint, color_w, (flags & 4) ? atlas_texel(S, u, v, (int)color_w, (int)tex_size) : 0u, c)) return false;
     h.color = c;
     if (flags & 2)
         h.emittance = unpack_unorm8(atlas_texel(S, u, v, (int)ne, (int)tex_size)).w;
     else
-        h.emittance = kEmittanceLut[ne & 0xFF];  // double site K/material.h:79, tabulated
+        h.emittance = em;  // double site K/material.h:79, tabulated
     h.spec = m5;
     return true;
 }
@@ -264,13 +274,13 @@ DEV Face face_map2(const Slabs& s, float tmin, f3 p) {  // AABB_full_intersect_m
 // position `pos` where a direction is expected (K/block.h:52), so the UV point is no + tmin*pos.
 // The material arrives as its 5 words (read from the material palette, or inline in block_info).
 DEV float cube_hit(const SceneView& S, unsigned m0, unsigned m1, unsigned m2, unsigned m3, unsigned m4, f3 no, f3 pos,
-                   f3 inv, Hit& h, int m5 = 0) {
+                   f3 inv, Hit& h, int m5, float em) {
     Slabs s = slabs(0, 1, 0, 1, 0, 1, no, inv);
     float tn = slab_near(s), tf = slab_far(s);
     if (tf < tn) return rt_nan();
     Face f = face_unit(s, tn, no + pos * tn);
     h.normal = f.n;  // written before the material test (K/block.h:59-60)
-    return material_eval(S, m0, m1, m2, m3, m4, f.u, f.v, h, m5) ? tn - kOffset : rt_nan();
+    return material_eval(S, m0, m1, m2, m3, m4, f.u, f.v, h, m5, em) ? tn - kOffset : rt_nan();
 }
 
 // AABB model (type 2) — K/block.h:66-91, K/primitives.h:165-260
@@ -356,36 +366,72 @@ DEV float quad_model_hit(const SceneView& S, int ptr, f3 no, f3 dir, Hit& h) {
 
 DEV bool material_sample8(const SceneView& S, int m8, float u, float v, Hit& h) {
     const int4 a = S.mat8[m8], b = S.mat8[m8 + 1];
-    return material_eval(S, a.x, a.y, a.z, a.w, b.x, u, v, h, b.y);
+    return material_eval(S, a.x, a.y, a.z, a.w, b.x, u, v, h, b.y, as_float(b.z));
 }
 
-// aabb_model_hit / quad_model_hit on the aligned records (same arithmetic, same order; rec = first record << 8 | count)
+// One primitive of a model block on the aligned records (SceneView::mat8), up to the material test: the geometry of
+// K/primitives.h:165-260 (a box: r0 r1 r2) / :263-319 (a quad: q0 .. q4), same arithmetic and order as aabb_model_hit /
+// quad_model_hit.  A candidate is {distance, normal, texture coordinates, material (word index)}; `best` is the nearest
+// primitive accepted so far.
+struct PrimCandidate {
+    float t;
+    f3 n;
+    float u, v;
+    int mat;
+};
+DEV bool box_candidate(const int4& r0, const int4& r1, const int4& r2, f3 no, f3 dir, f3 inv, float best, PrimCandidate& c) {
+    Slabs s = slabs(as_float(r0.x), as_float(r0.y), as_float(r0.z), as_float(r0.w), as_float(r1.x), as_float(r1.y), no, inv);
+    float tn = slab_near(s), tf = slab_far(s);
+    if (tf < tn) return false;
+    if (tn != tn || tn >= best || tn < -kEps) return false;
+    Face f = face_map2(s, tn, no + dir * tn);
+    const int fl_all = r1.z;
+    int mat = r1.w, fl = 0;  // +z keeps the east material with flags 0 (see aabb_model_hit)
+    if (f.n.x == 1) { mat = r1.w; fl = fl_all >> 4; }
+    if (f.n.z == -1) { mat = r2.x; fl = fl_all >> 8; }
+    if (f.n.x == -1) { mat = r2.y; fl = fl_all >> 12; }
+    if (f.n.y == 1) { mat = r2.z; fl = fl_all >> 16; }
+    if (f.n.y == -1) { mat = r2.w; fl = fl_all >> 20; }
+    if (fl & 8) return false;
+    float u = f.u, v = f.v;
+    if (fl & 4) u = 1 - u;
+    if (fl & 2) v = 1 - v;
+    if (fl & 1) { float t = u; u = v; v = t; }
+    c = PrimCandidate{tn, f.n, u, v, mat};
+    return true;
+}
+DEV bool quad_candidate(const int4& q0, const int4& q1, const int4& q2, const int4& q3, const int4& q4, f3 no, f3 dir, float best, PrimCandidate& c) {
+    const f3 qo = mk3(as_float(q0.x), as_float(q0.y), as_float(q0.z));
+    const f3 xv = mk3(as_float(q1.x), as_float(q1.y), as_float(q1.z));
+    const f3 yv = mk3(as_float(q2.x), as_float(q2.y), as_float(q2.z));
+    const f3 n = mk3(as_float(q3.x), as_float(q3.y), as_float(q3.z));
+    const float n_qo = as_float(q0.w), xx = as_float(q1.w), yy = as_float(q2.w);
+    float denom = dot(dir, n);
+    if (!(denom < -kEps)) return false;
+    float t = -(dot(no, n) - n_qo) / denom;
+    if (!(t > -kEps && t < best)) return false;
+    f3 pt = (no + dir * t) - qo;
+    float u = dot(pt, xv) / xx;
+    float v = dot(pt, yv) / yy;
+    if (!(u >= 0 && u <= 1 && v >= 0 && v <= 1)) return false;
+    float tu = as_float(q4.x) + (u * as_float(q4.y));
+    float tv = as_float(q4.z) + (v * as_float(q4.w));
+    c = PrimCandidate{t, n, tu, tv, q3.w};
+    return true;
+}
+
+// aabb_model_hit / quad_model_hit on the aligned records (same arithmetic, same order; rec = first word << 8 | count)
 DEV float aabb_model_hit_rec(const SceneView& S, int rec, f3 no, f3 dir, f3 inv, Hit& h) {
     const int boxes = rec & 0xFF, first = (int)((unsigned)rec >> 8);
     float best = rt_inf();
     bool hit = false;
     for (int i = 0; i < boxes; i++) {
-        const int4 r0 = S.aabb_rec[(first + i) * 3], r1 = S.aabb_rec[(first + i) * 3 + 1], r2 = S.aabb_rec[(first + i) * 3 + 2];
-        Slabs s = slabs(as_float(r0.x), as_float(r0.y), as_float(r0.z), as_float(r0.w), as_float(r1.x), as_float(r1.y), no, inv);
-        float tn = slab_near(s), tf = slab_far(s);
-        if (tf < tn) continue;
-        if (tn != tn || tn >= best || tn < -kEps) continue;
-        Face f = face_map2(s, tn, no + dir * tn);
-        const int fl_all = r1.z;
-        int mat = r1.w, fl = 0;  // +z keeps the east material with flags 0 (see aabb_model_hit)
-        if (f.n.x == 1) { mat = r1.w; fl = fl_all >> 4; }
-        if (f.n.z == -1) { mat = r2.x; fl = fl_all >> 8; }
-        if (f.n.x == -1) { mat = r2.y; fl = fl_all >> 12; }
-        if (f.n.y == 1) { mat = r2.z; fl = fl_all >> 16; }
-        if (f.n.y == -1) { mat = r2.w; fl = fl_all >> 20; }
-        if (fl & 8) continue;
-        float u = f.u, v = f.v;
-        if (fl & 4) u = 1 - u;
-        if (fl & 2) v = 1 - v;
-        if (fl & 1) { float t = u; u = v; v = t; }
-        if (material_sample8(S, mat, u, v, h)) {
-            h.normal = f.n;
-            best = tn;
+        const int4 r0 = S.mat8[first + i * 3], r1 = S.mat8[first + i * 3 + 1], r2 = S.mat8[first + i * 3 + 2];
+        PrimCandidate c;
+        if (!box_candidate(r0, r1, r2, no, dir, inv, best, c)) continue;
+        if (material_sample8(S, c.mat, c.u, c.v, h)) {
+            h.normal = c.n;
+            best = c.t;
             hit = true;
         }
     }
@@ -397,27 +443,12 @@ DEV float quad_model_hit_rec(const SceneView& S, int rec, f3 no, f3 dir, Hit& h)
     float best = rt_inf();
     bool hit = false;
     for (int i = 0; i < quads; i++) {
-        const int4* __restrict__ q = S.quad_rec + (first + i) * 6;
-        const int4 r0 = q[0], r1 = q[1], r2 = q[2], r4 = q[4];
-        const f3 qo = mk3(as_float(r0.x), as_float(r0.y), as_float(r0.z));
-        const f3 xv = mk3(as_float(r1.x), as_float(r1.y), as_float(r1.z));
-        const f3 yv = mk3(as_float(r2.x), as_float(r2.y), as_float(r2.z));
-        const f3 n = mk3(as_float(r4.x), as_float(r4.y), as_float(r4.z));
-        const float n_qo = as_float(r0.w), xx = as_float(r1.w), yy = as_float(r2.w);
-        float denom = dot(dir, n);
-        if (!(denom < -kEps)) continue;
-        float t = -(dot(no, n) - n_qo) / denom;
-        if (!(t > -kEps && t < best)) continue;
-        f3 pt = (no + dir * t) - qo;
-        float u = dot(pt, xv) / xx;
-        float v = dot(pt, yv) / yy;
-        if (!(u >= 0 && u <= 1 && v >= 0 && v <= 1)) continue;
-        const int4 r3 = q[3], r5 = q[5];
-        float tu = as_float(r3.x) + (u * as_float(r3.y));
-        float tv = as_float(r3.z) + (v * as_float(r3.w));
-        if (material_eval(S, r5.x, r5.y, r5.z, r5.w, r4.w, tu, tv, h, (int)((unsigned)r4.w >> 8))) {  // r4.w = emittance byte | word 5 << 8
-            h.normal = n;
-            best = t;
+        const int4* __restrict__ q = S.mat8 + first + i * 5;
+        PrimCandidate c;
+        if (!quad_candidate(q[0], q[1], q[2], q[3], q[4], no, dir, best, c)) continue;
+        if (material_sample8(S, c.mat, c.u, c.v, h)) {
+            h.normal = c.n;
+            best = c.t;
             hit = true;
         }
     }
@@ -433,14 +464,14 @@ DEV float block_hit(const SceneView& S, int block, int bx, int by, int bz, f3 po
         const int4 a = S.block_info[(unsigned)block], b = S.block_info[(unsigned)block + 1u];
         type = a.x;
         ptr = a.y;
-        if (type == 1) return cube_hit(S, a.z, a.w, b.x, b.y, b.z, no, pos, inv, h, b.w);  // word 7 of a cube: material word 5
+        if (type == 1) return cube_hit(S, a.z, a.w, b.x, b.y, b.z, no, pos, inv, h, b.w, as_float(a.y));  // of a cube, word 7: material word 5, word 1: its emittance
         if (b.w != 0) return type == 2 ? aabb_model_hit_rec(S, b.w, no, dir, inv, h) : quad_model_hit_rec(S, b.w, no, dir, h);
     } else {
         type = S.blocks[block];
         ptr = S.blocks[block + 1];
         if (type == 1) {
             const int* m = S.materials + ptr;
-            return cube_hit(S, m[0], m[1], m[2], m[3], m[4], no, pos, inv, h, m[5]);
+            return cube_hit(S, m[0], m[1], m[2], m[3], m[4], no, pos, inv, h, m[5], kEmittanceLut[m[4] & 0xFF]);
         }
     }
     switch (type) {

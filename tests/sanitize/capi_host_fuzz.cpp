@@ -121,15 +121,29 @@ static int fuzz_palettes(int rounds) {
                 if (!hostile) return fprintf(stderr, "round %d: a sound block was switched off\n", r), 1;
                 continue;
             }
-            if (e[0] != type || e[1] != ptr) return fprintf(stderr, "round %d: block %zu changed\n", r, k), 1;
+            // (of a full cube word 1 holds the material's emittance as a float instead of the pointer)
+            if (e[0] != type || (type != 1 && e[1] != ptr)) return fprintf(stderr, "round %d: block %zu changed\n", r, k), 1;
+            if (type == 1) {
+                float em;
+                memcpy(&em, &e[1], 4);
+                if (em != (float)((double)(p.M[(size_t)ptr + 4] & 0xFF) / 255.0)) return fprintf(stderr, "round %d: cube emittance\n", r), 1;
+            }
             if ((type == 2 || type == 3) && e[7] != 0) {
-                // the record path: first record and count have to lie inside the record array
+                // the record path: the primitives' words have to lie inside the record array (materials first, then boxes and quads),
+                // and so do the materials they point at
                 const int64_t first = (uint32_t)e[7] >> 8, count = e[7] & 0xFF;
-                const size_t words = type == 2 ? 12 : 24;
-                const std::vector<int32_t>& rec = type == 2 ? d.aabb_rec : d.quad_rec;
-                if ((size_t)(first + count) * words > rec.size()) return fprintf(stderr, "round %d: record range\n", r), 1;
+                const int64_t words = type == 2 ? 3 : 5, n_mat_words = (int64_t)d.mat8.size() / 4;
+                if (first < n_mat_words || (size_t)(first - n_mat_words + count * words) * 4 > d.prims.size()) return fprintf(stderr, "round %d: record range\n", r), 1;
+                for (int64_t i = 0; i < count; i++) {
+                    const int32_t* w = &d.prims[(size_t)(first - n_mat_words + i * words) * 4];
+                    for (int m = 0; m < (type == 2 ? 5 : 1); m++) {
+                        const int32_t at = type == 2 ? w[7 + m] : w[15];
+                        if (at < 0 || at + 2 > n_mat_words || at % 2) return fprintf(stderr, "round %d: material word\n", r), 1;
+                    }
+                }
                 recorded++;
             } else {
+                if ((type == 2 || type == 3) && d.all_on_records) return fprintf(stderr, "round %d: block %zu has no records but all_on_records is set\n", r, k), 1;
                 if (!packed_reads_inside(p, type, ptr)) return fprintf(stderr, "round %d: block %zu (type %d) left on a packed path that reads outside\n", r, k, type), 1;
                 packed++;
             }
