@@ -135,6 +135,7 @@ struct chunky_render {
     ShardView shard{0, 1, 256, 0};
     DevBuf own_fb, work_counter;
     DevBuf staging;  // render_pool: one launch's samples, [tile of 256 slots][pass][slot][3] floats
+    DevBuf cold;     // render_pool: the cold halves of the paths in flight (kernels.hpp pool_cold_bytes)
     DevBuf block_list;  // block shards under a kernel without the block mapping: this rank's pixels (ShardView::list)
     float* fb = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // timing brackets of enqueued launches
@@ -1552,12 +1553,20 @@ extern "C" int chunky_render_passes(chunky_render* r, const int32_t* seeds, int 
             HIP_TRY(hipEventRecord(slot.copied, r->ctx->stream));
             seeds_dev = (const int*)r->seed_buf.p;
         }
+        if (!r->cold.p) {
+            size_t cold_bytes = 0;
+            HIP_TRY(pool_cold_bytes(&cold_bytes));
+            if (cold_bytes) {
+                HIP_TRY(hipMalloc(&r->cold.p, cold_bytes));
+                r->cold.bytes = cold_bytes;
+            }
+        }
         hipEvent_t e0, e1;
         HIP_TRY(get_event(r, &e0));
         HIP_TRY(get_event(r, &e1));
         HIP_TRY(hipEventRecord(e0, r->ctx->stream));
         HIP_TRY(launch_render(r->kernel_variant, S, r->cam, r->opts, r->shard, ps, r->fb, (int*)r->work_counter.p, r->ctx->stream,
-                              &r->last_choice, (float*)r->staging.p, seeds_dev));
+                              &r->last_choice, (float*)r->staging.p, seeds_dev, r->cold.p));
         HIP_TRY(hipEventRecord(e1, r->ctx->stream));
         r->pending.emplace_back(e0, e1);
         done += ps.n;

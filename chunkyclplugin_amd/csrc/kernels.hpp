@@ -92,7 +92,9 @@ bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, b
 // P.n <= kMaxPassesPerLaunch with the seeds in P.seed, or (render_pool only) up to kMaxPoolPasses with the seeds in seeds_dev
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream,
-                         KernelChoice* chosen = nullptr, float* staging = nullptr, const int* seeds_dev = nullptr);
+                         KernelChoice* chosen = nullptr, float* staging = nullptr, const int* seeds_dev = nullptr, void* cold = nullptr);
+// bytes of the slab render_pool keeps the cold halves of its paths in (path_state.hpp WaveArgs::cold) on the CURRENT device
+hipError_t pool_cold_bytes(size_t* bytes);
 // the kernels behind render_pool (render_fallback.hip): render_waves, render_lanes
 hipError_t launch_fallback(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                            const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen);

@@ -475,6 +475,7 @@ struct WaveArgs {
     FastDiv div_sub;       // render_pool: division of a sample index by P.n x kSubBlock (the samples of one sub-block)
     FastDiv div_bw;        // render_pool: division of a tile index by the tiles per image row
     const int* seeds_dev;  // render_pool: the launch's seeds in device memory when it carries more passes than P.seed holds, else null
+    uint4* cold;           // render_pool (split records): per wave of the grid 128 paths x 32 bytes {sample index, rng, radiance} {radiance.z, throughput}
 };
 static_assert(sizeof(WaveArgs) <= 4096, "launch arguments must fit the 4 KB kernel-argument segment");
 typedef const WaveArgs __attribute__((address_space(4))) * WaveArgPtr;

@@ -171,8 +171,27 @@ DEV int phase_class(int st) {
 // A parked path is WORDS 16-byte words.  7 words without entity BVHs (the march-step count shares word 0 with the flags —
 // launch_pool sends draw depths above 65535 to render_waves — and the candidate block takes the place of the BVH cursor's
 // word); 8 with them; 9 for the extended integrator.  The flag bits sit where LaneState's bit-fields have them.
+// Split records (WORDS == 5, kernels without entity BVHs and without the extended integrator): only the HOT half of a path —
+// what MARCH and BLOCK read and write: ray, reciprocal direction, march state, the candidate, the surface record — lives in the
+// lane's registers and in its parked record; the COLD half — sample index, rng, radiance, throughput: SHADE's alone — stays put
+// in a slab in global memory (WaveArgs::cold), one 32-byte entry per path of the wave, and the path carries its entry's index
+// (L.pid, 7 bits of the flag word; the march-step count keeps 11: launch_pool sends draw depths above 2047 elsewhere).
+#ifndef CHUNKY_POOL_SPLIT
+#define CHUNKY_POOL_SPLIT 1
+#endif
+constexpr int kSplitStepBits = 11;
 template <int WORDS>
 DEV void pool_pack(const LaneState& L, uint4 (&v)[WORDS]) {
+    if constexpr (WORDS == 5) {
+        const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.cand_level << 10) |
+                              ((unsigned)L.steps << 14) | ((unsigned)L.pid << (14 + kSplitStepBits));
+        v[0] = make_uint4(misc, (unsigned)L.cand_data, __float_as_uint(L.o.x), __float_as_uint(L.o.y));
+        v[1] = make_uint4(__float_as_uint(L.o.z), __float_as_uint(L.d.x), __float_as_uint(L.d.y), __float_as_uint(L.d.z));
+        v[2] = make_uint4(__float_as_uint(L.inv.x), __float_as_uint(L.inv.y), __float_as_uint(L.inv.z), __float_as_uint(L.dist_march));
+        v[3] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
+        v[4] = make_uint4(__float_as_uint(L.h.color.x), __float_as_uint(L.h.color.y), __float_as_uint(L.h.color.z), __float_as_uint(L.h.emittance));
+        return;
+    }
     constexpr int H = WORDS == 7 ? 5 : 6;  // first of the two words of the main record
     const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.trace_hit << 10) |
                           ((unsigned)L.cand_level << 11) | ((unsigned)L.bvh_which << 15) |
@@ -189,6 +208,22 @@ DEV void pool_pack(const LaneState& L, uint4 (&v)[WORDS]) {
 }
 template <int WORDS>
 DEV void pool_unpack(LaneState& L, const uint4 (&v)[WORDS]) {
+    if constexpr (WORDS == 5) {
+        const unsigned misc = v[0].x;
+        L.depth = misc & 0xFFu; L.shadow = (misc >> 8) & 1u; L.oct_hit = (misc >> 9) & 1u; L.cand_level = (misc >> 10) & 15u;
+        L.steps = (int)((misc >> 14) & ((1u << kSplitStepBits) - 1u));
+        L.pid = (int)(misc >> (14 + kSplitStepBits));
+        L.cand_data = (int)v[0].y;
+        L.o = mk3(__uint_as_float(v[0].z), __uint_as_float(v[0].w), __uint_as_float(v[1].x));
+        L.d = mk3(__uint_as_float(v[1].y), __uint_as_float(v[1].z), __uint_as_float(v[1].w));
+        L.inv = mk3(__uint_as_float(v[2].x), __uint_as_float(v[2].y), __uint_as_float(v[2].z));
+        L.dist_march = __uint_as_float(v[2].w);
+        L.h.distance = __uint_as_float(v[3].x);
+        L.h.normal = mk3(__uint_as_float(v[3].y), __uint_as_float(v[3].z), __uint_as_float(v[3].w));
+        L.h.color = f4{__uint_as_float(v[4].x), __uint_as_float(v[4].y), __uint_as_float(v[4].z), 0.0f};
+        L.h.emittance = __uint_as_float(v[4].w);
+        return;
+    }
     constexpr int H = WORDS == 7 ? 5 : 6;
     if (WORDS > 8) {
         L.pend = mk3(__uint_as_float(v[WORDS - 1].x), __uint_as_float(v[WORDS - 1].y), __uint_as_float(v[WORDS - 1].z));
@@ -379,7 +414,8 @@ DEV void march_loop(const SceneView& Sm, const RenderOpts& Om, LaneState& L, Lan
 
 template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false>
 __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
-    constexpr int WORDS = EXT ? 9 : (BVH ? 8 : 7);  // 16-byte words of a parked path (pool_pack)
+    constexpr bool SPLIT = CHUNKY_POOL_SPLIT && !BVH && !EXT;  // hot half in registers / LDS, cold half in global memory
+    constexpr int WORDS = EXT ? 9 : (BVH ? 8 : (SPLIT ? 5 : 7));  // 16-byte words of a parked path (pool_pack)
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     extern __shared__ int lds[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -394,6 +430,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         P.list = P.tags + K;
         stacks.base = (int*)(base + K * 16 * WORDS + K * 8);
         if (BVH && lane < K) P.park[lane] = make_uint4(0u, 0u, (unsigned)(64 + lane) << 16, 0u);  // the parked slots' stack ids
+        if (SPLIT && lane < K) P.park[lane] = make_uint4((unsigned)(64 + lane) << (14 + kSplitStepBits), 0u, 0u, 0u);  // ... their cold entries
     }
     LdsStack stack{lds, 0};  // render_waves' per-lane stacks are not used here
     LaneState L;
@@ -552,6 +589,26 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             WaveArgPtr A = fresh_args();
             const SceneView S = arg_copy(&A->S);
             const RenderOpts O = arg_copy(&A->O);
+            const bool served = st == ST_SHADE || st == ST_FRESH;
+            uint4* cold = nullptr;
+            if (SPLIT) {  // the cold half comes in (defined for every lane: nothing of it stays live between executions)
+                cold = A->cold + ((size_t)(blockIdx.x * 4u + (unsigned)wave) * 128u + (unsigned)L.pid) * 2u;
+                uint4 c0 = make_uint4(0u, 0u, 0u, 0u), c1 = c0;
+                if (st == ST_SHADE) {
+#if defined(CHUNKY_COLD_NT)
+                    const unsigned* q = (const unsigned*)cold;
+                    c0 = make_uint4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
+                    c1 = make_uint4(__builtin_nontemporal_load(q + 4), __builtin_nontemporal_load(q + 5), __builtin_nontemporal_load(q + 6), __builtin_nontemporal_load(q + 7));
+#else
+                    c0 = cold[0];
+                    c1 = cold[1];
+#endif
+                }
+                L.sidx = (int)c0.x;
+                L.rng = c0.y;
+                L.radiance = mk3(__uint_as_float(c0.z), __uint_as_float(c0.w), __uint_as_float(c1.x));
+                L.throughput = mk3(__uint_as_float(c1.y), __uint_as_float(c1.z), __uint_as_float(c1.w));
+            }
             if (st == ST_SHADE) st = EXT ? shade_phase_ext<TREE, BVH>(S, O, L) : shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
             part_begin<STATS>(&parts);
             if (st == ST_NEXT) {  // the path is finished: its radiance waits in the staging array for fold_kernel
@@ -617,6 +674,18 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             }
             part_end<STATS>(&parts, PT_NEWSAMPLE);
             if (st == ST_SETUP) st = trace_setup<END, false>(S, L);
+            if (SPLIT && served && (st == ST_MARCH || st == END)) {  // ... and goes back for the paths that live on
+#if defined(CHUNKY_COLD_NT)
+                unsigned* q = (unsigned*)cold;
+                __builtin_nontemporal_store((unsigned)L.sidx, q); __builtin_nontemporal_store(L.rng, q + 1);
+                __builtin_nontemporal_store(__float_as_uint(L.radiance.x), q + 2); __builtin_nontemporal_store(__float_as_uint(L.radiance.y), q + 3);
+                __builtin_nontemporal_store(__float_as_uint(L.radiance.z), q + 4); __builtin_nontemporal_store(__float_as_uint(L.throughput.x), q + 5);
+                __builtin_nontemporal_store(__float_as_uint(L.throughput.y), q + 6); __builtin_nontemporal_store(__float_as_uint(L.throughput.z), q + 7);
+#else
+                cold[0] = make_uint4((unsigned)L.sidx, L.rng, __float_as_uint(L.radiance.x), __float_as_uint(L.radiance.y));
+                cold[1] = make_uint4(__float_as_uint(L.radiance.z), __float_as_uint(L.throughput.x), __float_as_uint(L.throughput.y), __float_as_uint(L.throughput.z));
+#endif
+            }
             part_end<STATS>(&parts, PT_SETUP);
         }
         if (STATS) {
@@ -708,7 +777,7 @@ __global__ void __launch_bounds__(256) clear_foreign_kernel(ShardView T, int wid
 // the generic tree form only).
 static hipError_t launch_pool(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                               const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
-                              float* staging, const int* seeds_dev) {
+                              float* staging, const int* seeds_dev, void* cold) {
     const int block = 256;
     int n_cu = 0;
     if (hipError_t e = current_device_cus(&n_cu)) return e;
@@ -727,7 +796,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     typedef void (*Kernel)(WaveArgs);
     Kernel k;
     const bool ext = opts_extended(O);  // EXPERIMENTAL light-transport options: their own instantiations
-    int words = bvh ? 8 : 7;
+    int words = bvh ? 8 : (CHUNKY_POOL_SPLIT ? 5 : 7);
     if (ext) {
         if (tree != 17 && tree != 18) tree = -1;
         words = 9;
@@ -771,7 +840,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     int occ = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, block, lds);
     if (e != hipSuccess) return e;
-    const int bpc = occ > 0 ? occ : 1;
+    const int bpc = occ > 0 ? (occ > 8 ? 8 : occ) : 1;  // (pool_cold_bytes sizes the cold slab for eight workgroups per CU)
     const long long n_tiles = pool_tiles(T, C.width, C.height);
     const long long n_samples = n_tiles * kSampleTile * P.n;  // tiles at the image's edges are padded
     // a wave keeps 64 + park paths in flight: no more workgroups than the samples can feed
@@ -785,7 +854,8 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     if (e != hipSuccess) return e;
     WaveArgs A{S, C, O, T, P, WorkQueue{work_counter}, res, (unsigned long long*)(work_counter + 2), (unsigned)depth, staging, (unsigned)n_samples,
                (unsigned)((n_tiles + kXcdRanges - 1) / kXcdRanges * kSampleTile * P.n), fast_div((unsigned)P.n * (unsigned)kSubBlock),
-               fast_div((unsigned)((C.width + kTileEdge - 1) >> kTileLog)), seeds_dev};
+               fast_div((unsigned)((C.width + kTileEdge - 1) >> kTileLog)), seeds_dev, (uint4*)cold};
+    if (CHUNKY_POOL_SPLIT && !bvh && !ext && !cold) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, stream, A);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -798,16 +868,16 @@ bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, b
     const bool any_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
     // render_pool: always without entity BVHs; with them when they could be re-laid out (rt_device.hpp bvh_rec / tri_rec)
     // (its 7-word parked record counts march steps in 16 bits: a larger draw depth runs render_waves)
-    const bool steps_fit = any_bvh || opts_extended(O) || O.draw_depth <= 65535;
+    const bool steps_fit = any_bvh || opts_extended(O) || O.draw_depth <= (CHUNKY_POOL_SPLIT ? (1 << kSplitStepBits) - 1 : 65535);
     return !(variant & 2) && !(variant & 8) && have_queue_and_staging && steps_fit &&
            (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1)));
 }
 hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                          const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
-                         float* staging, const int* seeds_dev) {
+                         float* staging, const int* seeds_dev, void* cold) {
     if (pool_kernel_applies(variant, S, O, work_counter && staging)) {
         if (P.n > kMaxPoolPasses || (P.n > kMaxPassesPerLaunch && !seeds_dev)) return hipErrorInvalidValue;
-        return launch_pool(variant, S, C, O, T, P, res, work_counter, stream, chosen, staging, P.n > kMaxPassesPerLaunch ? seeds_dev : nullptr);
+        return launch_pool(variant, S, C, O, T, P, res, work_counter, stream, chosen, staging, P.n > kMaxPassesPerLaunch ? seeds_dev : nullptr, cold);
     }
     if (P.n > kMaxPassesPerLaunch) return hipErrorInvalidValue;
     if (T.world != 1 && T.tile == 0) {
@@ -818,6 +888,14 @@ hipError_t launch_render(int variant, const SceneView& S, const CameraView& C, c
         return launch_fallback(variant, S, C, O, F, P, res, work_counter, stream, chosen);
     }
     return launch_fallback(variant, S, C, O, T, P, res, work_counter, stream, chosen);
+}
+
+hipError_t pool_cold_bytes(size_t* bytes) {
+    int n_cu = 0;
+    if (hipError_t e = current_device_cus(&n_cu)) return e;
+    // the grid never holds more than 8 workgroups of four waves per CU (six at the registers the kernel has); 128 paths x 32 bytes per wave
+    *bytes = CHUNKY_POOL_SPLIT ? (size_t)n_cu * 8 * 4 * 128 * 32 : 0;
+    return hipSuccess;
 }
 
 hipError_t launch_gather(bool pack, const ShardView& T, int width, int height, float* fb, float* packed, hipStream_t stream) {
