@@ -1,3 +1,4 @@
 export CHUNKY_ORACLE_NO_BUILD=1
-bash tools/ab.sh "default bvh6k8 bvh6k4 bvh5k8" entities entities4k > gpurun_out/r06_bvh_occupancy_ab.txt 2>&1
-cat gpurun_out/r06_bvh_occupancy_ab.txt
+(timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_timed_kernels.py -m gpu -q -x --timeout 600 2>&1 | tail -3)
+bash tools/ab.sh "base default" bench benchmark indoor entities
+cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-roofline --no-extras --steps 6 > /tmp/kt.log 2>&1; find /tmp/kt -name "*kernel_stats.csv" | head -1 | xargs head -4
