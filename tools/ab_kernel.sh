@@ -10,5 +10,5 @@ import json,sys; d=json.load(sys.stdin); print('variant $v stats Msamples/s %.1f
 done
 for rep in 1 2; do for v in "$@"; do
   timeout 120 python bench.py --no-cpu --no-extras --no-roofline --steps 8 --kernel $v 2>/dev/null | python -c "
-import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('variant', d['config']['kernel_variant'], 'Msamples/s', d['value'], 'launch_ms', d['roofline']['launch_ms'])" | tee -a $OUT/ab.txt
+import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('variant $v', 'Msamples/s', d['value'], 'launch_ms', d['roofline']['launch_ms'])" | tee -a $OUT/ab.txt
 done; done
