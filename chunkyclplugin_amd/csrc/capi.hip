@@ -306,10 +306,13 @@ static int group_wait(chunky_ctx* g, const std::vector<int>& devices, const std:
 // machine, this process and this library file demonstrably move the right bytes; anything else — an error code, a hang, a
 // wrong byte — is found HERE, at group creation, where the answer is "peer copies, and chunky_group_transport says why",
 // not in the middle of a render.
-static int group_probe_rccl(chunky_ctx* g) {
+// (`send` / `recv` belong to the caller: if the probe ends in a hung exchange they must outlive the abort — hipFree would wait
+// for the stuck kernel)
+static int group_probe_rccl(chunky_ctx* g, std::vector<DevBuf>& send, std::vector<DevBuf>& recv) {
     const RcclApi& api = rccl_api();
     const size_t n = g->members.size(), count = 1024;
-    std::vector<DevBuf> send(n), recv(n);
+    send.resize(n);
+    recv.resize(n);
     std::vector<int> devices;
     std::vector<hipStream_t> streams;
     std::vector<float> host(count);
@@ -394,7 +397,8 @@ static void group_open_rccl(chunky_ctx* g, const int* devices, int n) {
         g->transport_detail = std::string("peer copies: ncclCommInitAll: ") + api.str(rc);
         return;
     }
-    if (probe && group_probe_rccl(g) != CHUNKY_OK) {
+    std::vector<DevBuf> probe_send, probe_recv;  // freed at the end of this function: after the abort and the drain below
+    if (probe && group_probe_rccl(g, probe_send, probe_recv) != CHUNKY_OK) {
         const std::string why = tls_error;
         group_close_rccl(g, true);  // abort first (a hung probe kernel is unblocked by nothing else), then drain
         for (chunky_ctx* m : g->members) {
