@@ -2155,9 +2155,9 @@ extern "C" int chunky_widetree_lookup(const int32_t* tree, int64_t n_ints, int d
             e = (int32_t)wt.data[(size_t)e + (size_t)(((((x >> sh) & m) << b) | ((y >> sh) & m)) << b | ((z >> sh) & m))];
         }
         if (e >= 0) return fail(CHUNKY_E_INVALID, "wide tree: lookup did not end in a leaf");
-        level_out[i] = (e >> 27) & 15;
-        uint32_t code = (uint32_t)e & kWideAny;
-        data_out[i] = code == kWideAny ? 0x7FFFFFFE : (int32_t)(code & kWidePtrMask);
+        level_out[i] = (e >> kWideLevelShift) & 15;
+        const uint32_t ptr = (uint32_t)e & kWidePtrMask;
+        data_out[i] = ptr == kWidePtrMask ? 0x7FFFFFFE : (int32_t)ptr;
     }
     return CHUNKY_OK;
 }

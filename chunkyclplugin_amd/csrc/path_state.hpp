@@ -55,8 +55,14 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
 #pragma unroll
             for (int i = 0; i < N3; i++) {
                 if (e >= 0) {
+                    // index in the 8^3 node = x:3 y:3 z:3 of the cell's bits [sh, sh + 3): each field shifted into place, then two
+                    // v_and_or_b32 (the compiler's form is three v_and and a v_or3)
                     const int sh = 3 * (N3 - 1 - i);
-                    const unsigned idx = (((unsigned)bx >> sh) & 7u) << 6 | (((unsigned)by >> sh) & 7u) << 3 | (((unsigned)bz >> sh) & 7u);
+                    const unsigned xs = sh <= 6 ? (unsigned)bx << (6 - sh) : (unsigned)bx >> (sh - 6);
+                    const unsigned ys = sh <= 3 ? (unsigned)by << (3 - sh) : (unsigned)by >> (sh - 3);
+                    unsigned idx = ((unsigned)bz >> sh) & 7u;
+                    asm("v_and_or_b32 %0, %1, 56, %0" : "+v"(idx) : "v"(ys));
+                    asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(idx) : "v"(xs), "s"(0x1c0u));  // (no literal operands in VOP3 on gfx9: the mask rides in an SGPR)
                     e = *(const int*)((const char*)tree + (((unsigned)e + idx) << 2));
                 }
             }
@@ -70,10 +76,11 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
                 e = (int)tree[(unsigned)e + ((((ix << b) | iy) << b) | iz)];  // unsigned: 32-bit offset off an SGPR base
             }
         }
-        // three field extractions: the builder's annotation pass (widetree.cpp) has set kind 2 on air and on
-        // pointers outside the block palette, and ANY_TYPE carries kind 3; `data` means something for kinds 0, 1 only
-        level = (e >> 27) & 15;
-        kind = (int)(((unsigned)e >> 25) & 3u);
+        // two field extractions and ONE compare: the builder's annotation pass (widetree.cpp) has set the no-hit bit (30) on air,
+        // on pointers outside the block palette and on ANY_TYPE, so "a leaf that can be hit" is entry < 0xC0000000 as unsigned;
+        // `data` means something for such leaves only (callers only ever ask kind < 2)
+        level = (e >> 26) & 15;
+        kind = (unsigned)e >= 0xC0000000u ? 2 : 0;
         data = (int)((unsigned)e & 0x1FFFFFFu);
     }
 }
@@ -402,14 +409,20 @@ DEV int trace_setup(const SceneView& S, LaneState& L) {
 typedef unsigned long long LaneMask;
 DEV bool in_mask(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// The world's edge, 2^depth, as a value the optimiser cannot see through (it would turn "x < 1 << depth" back into a shift and
+// a compare): made once, outside the march loop.
+DEV unsigned world_edge(const SceneView& S) {
+    unsigned edge = 1u << S.octree_depth;
+    asm("" : "+s"(edge));
+    return edge;
+}
 template <int TREE, bool GUARD = true>
 DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneMask marching, LaneMask& cand_out,
-                    LaneMask& live_out, int& data, int& level, const LaneMask* far_masks = nullptr) {
-    const int depth = S.octree_depth;
+                    LaneMask& live_out, int& data, int& level, const unsigned edge, const LaneMask* far_masks = nullptr) {
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
     int bx = floor_to_int(po.x), by = floor_to_int(po.y), bz = floor_to_int(po.z);
-    const bool inside = ((bx | by | bz) >> depth) == 0;
+    const bool inside = (unsigned)(bx | by | bz) < edge;  // every coordinate in [0, 2^depth): one compare (a negative one has the top bit set)
     const LaneMask live = marching & __ballot(L.steps < O.draw_depth) & __ballot(!(L.dist_march > L.h.distance)) & __ballot(inside);
     int kind;
     leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, inside);
@@ -421,7 +434,8 @@ DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneM
     const float step = leaf_exit_distance<GUARD>(L, far, po, bx, by, bz, level) + kOffset;  // K/octree.h:103-106
     const bool advance = in_mask(go);
     L.dist_march = advance ? L.dist_march + step : L.dist_march;
-    L.steps = advance ? L.steps + 1 : L.steps;
+    // steps += 1 for the lanes of `go`: the mask is the carry-in of one add
+    asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(L.steps) : "s"(go) : "vcc");
     cand_out = cand;
     live_out = live;
 }

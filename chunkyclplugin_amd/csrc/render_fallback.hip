@@ -475,9 +475,10 @@ __global__ void __launch_bounds__(256, (BVH ? 4 : 5)) render_waves(WaveArgs unus
                 const LaneMask entered = __ballot(st == ST_MARCH);
                 LaneMask marching = entered, to_block = 0;
                 int data, level;
+                const unsigned edge = world_edge(Sm);
                 do {
                     LaneMask cand, live;
-                    march_step<TREE>(Sm, Om, L, marching, cand, live, data, level);
+                    march_step<TREE>(Sm, Om, L, marching, cand, live, data, level, edge);
                     nb += __popcll(cand);
                     ne += __popcll(marching & ~live);
                     to_block |= cand;

@@ -106,7 +106,7 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
                             code = kWideAny;
                         else if (code >= kWidePtrMask)
                             return *why = kPtr, false;
-                        d[(size_t)slot] = kWideLeaf | ((uint32_t)lvl << 27) | code;
+                        d[(size_t)slot] = kWideLeaf | ((uint32_t)lvl << kWideLevelShift) | code;
                     } else {
                         if (j.level + 1 >= nlev) return *why = kTree, false;  // a branch below level 0
                         const int64_t child = (int64_t)d.size();
@@ -124,15 +124,14 @@ bool build_wide_tree(const int32_t* oct, int64_t n, int depth, const int* level_
 void annotate_wide_tree(WideTree* t, const int32_t* blocks, int64_t n) {
     for (uint32_t& e : t->data) {
         if (!(e & kWideLeaf)) continue;
-        const uint32_t code = e & kWideAny;
-        if (code == kWideAny) continue;
-        const uint32_t ptr = code & kWidePtrMask;
+        const uint32_t ptr = e & kWidePtrMask;
+        if (ptr == kWidePtrMask) continue;  // ANY_TYPE: marked when the tree was built
         uint32_t kind = 2;
         if (ptr != 0 && (int64_t)ptr + 1 < n) {
             const int32_t type = blocks[ptr];
             kind = type == 1 ? 0u : ((type == 2 || type == 3) ? 1u : 2u);
         }
-        e = (e & ~(3u << kWideKindShift)) | (kind << kWideKindShift);
+        e = (e & ~(kWideNoHit | kWideKindLow)) | ((kind & 2u) ? kWideNoHit : 0u) | ((kind & 1u) ? kWideKindLow : 0u);
     }
 }
 

@@ -7,12 +7,13 @@
 // axis at level i, i.e. a node at level i is a dense (2^bits[i])^3 grid of 32-bit entries:
 //
 //   entry >= 0 : int offset of the child node (level i+1) inside the array
-//   entry <  0 : leaf — bits 30..27 = level of the octree leaf that contains the cell (its cube has
-//                edge 2^level; needed for the leaf-exit box of K/octree.h:103-106),
-//                bits 26..25 = kind of the block (filled in by annotate_wide_tree once the block
-//                palette is known): 0 full cube (K/block.h:48), 1 AABB/quad model (:66,:92),
-//                2 never intersects (model type 0/unknown, K/block.h:44-47), 3 ANY_TYPE (K/block.h:32);
-//                bits 24..0 = block-palette pointer (K/octree.h:88); 0x7FFFFFF = ANY_TYPE
+//   entry <  0 : leaf — bit 30 = the block cannot be hit (filled in by annotate_wide_tree once the block palette is
+//                known: air, model type 0 / unknown, K/block.h:44-47, a pointer outside the palette; ANY_TYPE,
+//                K/block.h:32, from the start) — so "leaf that can be hit" is ONE unsigned compare, entry < 0xC0000000;
+//                bits 29..26 = level of the octree leaf that contains the cell (its cube has edge 2^level; needed
+//                for the leaf-exit box of K/octree.h:103-106); bit 25 = the low bit of the block's kind (0 full
+//                cube K/block.h:48 / 1 AABB or quad model :66,:92; of a block that cannot be hit: 0 / 1 = ANY_TYPE);
+//                bits 24..0 = block-palette pointer (K/octree.h:88); all ones = ANY_TYPE
 //
 // With bits = {3,3,3} a depth-9 world needs at most 3 dependent loads per lookup instead of 9.
 #pragma once
@@ -24,9 +25,11 @@ namespace chunky {
 
 constexpr int kWideMaxLevels = 6;
 constexpr uint32_t kWideLeaf = 0x80000000u;
-constexpr uint32_t kWideAny = 0x7FFFFFFu;
-constexpr uint32_t kWidePtrMask = 0x1FFFFFFu;
-constexpr int kWideKindShift = 25;
+constexpr uint32_t kWideNoHit = 0x40000000u;   // with kWideLeaf: (entry as unsigned) >= kWideLeaf | kWideNoHit <=> the march walks on
+constexpr int kWideLevelShift = 26;
+constexpr uint32_t kWideKindLow = 0x2000000u;
+constexpr uint32_t kWidePtrMask = 0x1FFFFFFu;   // as a pointer value: ANY_TYPE
+constexpr uint32_t kWideAny = kWideNoHit | kWideKindLow | kWidePtrMask;
 
 struct WideTree {
     std::vector<uint32_t> data;
