@@ -154,9 +154,12 @@ DEV int shade_phase_ext(const SceneView& S, const RenderOpts& O, LaneState& L) {
 // staging array [pass][pixel][3] and fold_kernel applies the running mean of K/rayTracer.cl:109-112 in pass order
 // afterwards — the same float recurrence in the same order, so the image is bit-identical, and the pixel groups, LDS
 // rings and hand-over rounds of render_waves (15 % of its time) do not exist here.
-enum : int {
-    ST_FRESH = 12   // the lane (or parked slot) holds no path and wants a sample; served by the SHADE branch
-};
+// A lane (or parked slot) that holds no path and wants a sample is "fresh": state ST_SHADE — the SHADE branch serves it — with
+// the path depth 255 (kFreshDepth; launch_pool sends max_depth above 254 to the other kernels).  The states a path can be in
+// between two phase executions are then 0 MARCH, 1 BLOCK, 2 SHADE, 3 DONE (+ ST_BVH / ST_LEAF with entity BVHs): the state IS its
+// class, the census is one compare per class, and the vote and the swap need no classification (round 6: a fresh path used to be
+// a state of its own, 12, and every iteration classified both state vectors through a chain of compares and branches).
+constexpr unsigned kFreshDepth = 255u;
 
 struct PoolLds {
     uint4* park;  // [WORDS][K]: 16-byte word g of slot s at park[g * K + s] (consecutive lanes, consecutive 16 bytes)
@@ -164,8 +167,9 @@ struct PoolLds {
     int* list;    // [K] scratch: the slots taking part in a swap, by rank
 };
 
+template <bool BVH>
 DEV int phase_class(int st) {
-    return st == ST_MARCH ? 0 : (st == ST_BLOCK ? 1 : (st == ST_DONE ? 3 : ((st == ST_BVH || st == ST_LEAF) ? 5 : 2)));
+    return BVH && st >= ST_BVH ? 5 : st;  // (ST_MARCH 0, ST_BLOCK 1, ST_SHADE 2, ST_DONE 3; the entity walk's states are one class)
 }
 
 // A parked path is WORDS 16-byte words.  7 words without entity BVHs (the march-step count shares word 0 with the flags —
@@ -235,9 +239,10 @@ DEV void wave_lds_fence() {
 // 16-byte groups in one burst and writes its own over them.
 template <int K, int WORDS = 8>
 DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) {
+    constexpr bool BVH = WORDS == 8 || WORDS == 9;  // (the extended integrator's 9-word record carries the walk's fields too)
     const bool done = st == ST_DONE;
-    const bool out = phase_class(st) != X;
-    const bool in = lane < K && phase_class(ptag) == X;
+    const bool out = phase_class<BVH>(st) != X;
+    const bool in = lane < K && phase_class<BVH>(ptag) == X;
     const LaneMask m_done = __ballot(done), m_out = __ballot(out && !done), m_in = __ballot(in);
     const int n_done = __popcll(m_done), n_out = n_done + __popcll(m_out), n_in = __popcll(m_in);
     const int n = n_out < n_in ? n_out : n_in;
@@ -394,7 +399,8 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         P.tags = (int*)(base + K * 16 * WORDS);
         P.list = P.tags + K;
         stacks.base = (int*)(base + K * 16 * WORDS + K * 8);
-        if (BVH && lane < K) P.park[lane] = make_uint4(0u, 0u, (unsigned)(64 + lane) << 16, 0u);  // the parked slots' stack ids
+        // every parked slot starts fresh (depth 255 in its flag word); with entity BVHs it also owns a to-visit stack
+        if (lane < K) P.park[lane] = make_uint4(0u, 0u, kFreshDepth | (WORDS == 7 ? 0u : (unsigned)(64 + lane) << 16), 0u);
     }
     LdsStack stack{lds, 0};  // render_waves' per-lane stacks are not used here
     LaneState L;
@@ -418,7 +424,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
     L.serial = 0;
     L.steps = 0;
     L.rng = 0;
-    L.depth = 0;
+    L.depth = kFreshDepth;
     L.shadow = false;
     L.dist_march = 0;
     L.radiance = mk3(0, 0, 0);
@@ -436,8 +442,8 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
     if (STATS) t_begin = __builtin_amdgcn_s_memtime();
     XcdClaim claim{xcd_first_range(), 0u, 0u};
     int ranges_tried = 0;  // ranges this wave has found empty
-    int st = ST_FRESH;
-    int ptag = lane < K ? ST_FRESH : ST_DONE;
+    int st = ST_SHADE;  // fresh (L.depth == kFreshDepth): the first SHADE execution hands out samples
+    int ptag = lane < K ? ST_SHADE : ST_DONE;
     wave_lds_fence();
     for (;;) {
         if (BVH && __ballot(st == ST_TRACED)) {  // octree part of some traces just ended: entity BVHs next
@@ -447,7 +453,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         // the pool's census: paths waiting for each phase, in lanes and parked
         const int c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
         const int c_block = count_lanes(st == ST_BLOCK) + count_lanes(ptag == ST_BLOCK);
-        const int c_shade = count_lanes(st == ST_SHADE || st == ST_FRESH) + count_lanes(ptag == ST_SHADE || ptag == ST_FRESH);
+        const int c_shade = count_lanes(st == ST_SHADE) + count_lanes(ptag == ST_SHADE);  // (fresh paths included)
         const int c_bvh = BVH ? count_lanes(st == ST_BVH) + count_lanes(ptag == ST_BVH) : 0;
         const int c_leaf = BVH ? count_lanes(st == ST_LEAF) + count_lanes(ptag == ST_LEAF) : 0;
         if ((c_march | c_block | c_shade | c_bvh | c_leaf) == 0) break;  // every lane and every slot is ST_DONE
@@ -552,11 +558,13 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                 prof[4] -= (unsigned long long)n_exec;
             }
         } else {
-            n_exec = count_lanes(st == ST_SHADE || st == ST_FRESH);
+            n_exec = count_lanes(st == ST_SHADE);
             WaveArgPtr A = fresh_args();
             const SceneView S = arg_copy(&A->S);
             const RenderOpts O = arg_copy(&A->O);
-            if (st == ST_SHADE) st = EXT ? shade_phase_ext<TREE, BVH>(S, O, L) : shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
+            const bool served = st == ST_SHADE;
+            bool fresh = served && L.depth == kFreshDepth;  // holds no path: wants a sample
+            if (served && !fresh) st = EXT ? shade_phase_ext<TREE, BVH>(S, O, L) : shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
             part_begin<STATS>(&parts);
             if (st == ST_NEXT) {  // the path is finished: its radiance waits in the staging array for fold_kernel
                 // streamed past the caches (nt): written once, read once by fold_kernel; the L2 stays with the tree
@@ -576,19 +584,20 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                 __builtin_nontemporal_store(L.radiance.y, out + 1);
                 __builtin_nontemporal_store(L.radiance.z, out + 2);
 #endif
-                st = ST_FRESH;
+                fresh = true;
             }
             part_end<STATS>(&parts, PT_DEPOSIT);
             // ---- new samples (K/rayTracer.cl:55-91).  Sample index = (tile of kSampleTile pixel slots, pass, slot in tile): a
             //      tile gets all its passes before the next tile starts, so the paths in flight on the whole GPU cover a few
             //      thousand neighbouring pixels — a part of the scene that stays in the 4 MB L2s (pass-major order spread
             //      them over a third of the image: L2 hit rate 91 %, 66 GB of fabric reads per launch instead of 4) ----
-            const bool need = st == ST_FRESH;
+            const bool need = fresh;
             const unsigned sidx = xcd_claim(A->Q.next + kXcdCounters, claim, ranges_tried, need, A->xcd_stripe, A->n_samples);  // convergent
             if (need && sidx != kClaimNone) {
                 const unsigned n_samples = A->n_samples;
                 if (sidx >= n_samples) {
                     st = ST_DONE;
+                    fresh = false;
                 } else {
                     const CameraView C = arg_copy(&A->C);
                     const ShardView T = arg_copy(&A->T);
@@ -616,10 +625,15 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                         L.after_nee = false;
                         L.h.distance = rt_inf();
                         st = ST_SETUP;
+                        fresh = false;
                     }
                 }
             }
             part_end<STATS>(&parts, PT_NEWSAMPLE);
+            if (fresh) {  // no sample this time (the tail of a batch, a padding slot): it asks again at the next SHADE
+                st = ST_SHADE;
+                L.depth = kFreshDepth;
+            }
             if (st == ST_SETUP) st = trace_setup<END, false>(S, L);
             part_end<STATS>(&parts, PT_SETUP);
         }
@@ -808,7 +822,7 @@ bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, b
     const bool any_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
     // render_pool: always without entity BVHs; with them when they could be re-laid out (rt_device.hpp bvh_rec / tri_rec)
     // (its 7-word parked record counts march steps in 16 bits: a larger draw depth runs render_waves)
-    const bool steps_fit = any_bvh || opts_extended(O) || O.draw_depth <= 65535;
+    const bool steps_fit = (any_bvh || opts_extended(O) || O.draw_depth <= 65535) && O.max_depth <= 254;  // (path depth 255 marks a fresh path)
     return !(variant & 2) && !(variant & 8) && have_queue_and_staging && steps_fit &&
            (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1)));
 }
