@@ -281,10 +281,7 @@ __host__ __device__ inline long long pool_tiles(const ShardView& T, int width, i
 }
 // lanes of the wave for which p holds, as a 32-bit scalar (a 64-bit popcount makes the compiler do the
 // vote comparisons on the VALU: there is no 64-bit scalar less-than)
-DEV int count_lanes(bool p) {
-    const unsigned long long m = __ballot(p);
-    return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
-}
+DEV int count_lanes(bool p) { return (int)__builtin_popcountll(__ballot(p)); }  // one s_bcnt1_i32_b64
 enum : int {
     ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2,  // voted phases (+ ST_BVH)
     ST_BVH = 9,     // at a node of an entity BVH: inner-node visits are voted as one phase,

@@ -240,17 +240,24 @@ DEV void wave_lds_fence() {
 template <int K, int WORDS = 8>
 DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) {
     constexpr bool BVH = WORDS == 8 || WORDS == 9;  // (the extended integrator's 9-word record carries the walk's fields too)
-    const bool done = st == ST_DONE;
-    const bool out = phase_class<BVH>(st) != X;
-    const bool in = lane < K && phase_class<BVH>(ptag) == X;
-    const LaneMask m_done = __ballot(done), m_out = __ballot(out && !done), m_in = __ballot(in);
-    const int n_done = __popcll(m_done), n_out = n_done + __popcll(m_out), n_in = __popcll(m_in);
+    // who trades, as lane masks in scalar registers (mask algebra on the scalar unit; the vector unit only compares)
+    constexpr LaneMask kSlots = K >= 64 ? ~0ull : ((1ull << K) - 1ull);            // lane j < K speaks for parked slot j
+    const LaneMask m_done = __ballot(st == ST_DONE);
+    const LaneMask m_goes = __ballot(phase_class<BVH>(st) != X);                   // (ST_DONE is a class of its own: included)
+    const LaneMask m_in = __ballot(phase_class<BVH>(ptag) == X) & kSlots;
+    const int n_out = (int)__popcll(m_goes), n_in = (int)__popcll(m_in);
     const int n = n_out < n_in ? n_out : n_in;
     if (n == 0) return 0;  // wave-uniform
     const int r_in = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_in, 0u));
-    const LaneMask m_mine = done ? m_done : m_out;
-    const int r_out = (done ? 0 : n_done) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_mine, 0u));
-    const bool comes = in && r_in < n, goes = out && r_out < n;
+    int r_out;
+    if (m_done == 0) {  // (wave-uniform) the usual case: lanes go out in lane order
+        r_out = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_goes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_goes, 0u));
+    } else {            // the last moments of a launch: lanes that hold nothing any more give their place up first
+        const bool done = st == ST_DONE;
+        const LaneMask m_mine = done ? m_done : (m_goes & ~m_done);
+        r_out = (done ? 0 : (int)__popcll(m_done)) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_mine, 0u));
+    }
+    const bool comes = in_mask(m_in) && r_in < n, goes = in_mask(m_goes) && r_out < n;
     if (comes) P.list[r_in] = lane | (ptag << 8);  // slot and tag of the r-th path that comes in
     if (goes) P.tags[r_out] = st;                  // tag of the r-th path that goes out
     wave_lds_fence();
@@ -460,8 +467,13 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         // at most 64 paths run at once; among phases that can fill the wave SHADE and BLOCK go first (they feed the march)
         const int v_march = (c_march < 64 ? c_march : 64) * kWMarch, v_block = (c_block < 64 ? c_block : 64) * kWBlock,
                   v_shade = (c_shade < 64 ? c_shade : 64) * kWShade;
-        int X = (v_shade >= v_block && v_shade >= v_march) ? 2 : (v_block >= v_march ? 1 : 0);
-        int v_best = X == 2 ? v_shade : (X == 1 ? v_block : v_march);
+        // (written as integer arithmetic: as a chain of ?: on wave-uniform bools the compiler routes the choice through a VGPR)
+        int X = (int)((unsigned)(v_march - v_block - 1) >> 31);  // 1 when v_block >= v_march, else 0
+        int v_best = v_block > v_march ? v_block : v_march;
+        if (v_shade >= v_best) {
+            X = 2;
+            v_best = v_shade;
+        }
         if (BVH) {  // the walk through the entity BVHs (inner-node and leaf visits together) is one class of the pool
             const int c_walk = c_bvh + c_leaf;
             const int v_walk = (c_walk < 64 ? c_walk : 64) * kWWalk;
