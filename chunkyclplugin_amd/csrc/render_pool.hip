@@ -452,18 +452,23 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
     int st = ST_SHADE;  // fresh (L.depth == kFreshDepth): the first SHADE execution hands out samples
     int ptag = lane < K ? ST_SHADE : ST_DONE;
     wave_lds_fence();
-    for (;;) {
+    // the pool's census: paths waiting for each phase, in lanes and parked (taken at the END of an iteration, so that the loop has
+    // one exit, at its head: a break in mid-loop makes the compiler define every loop-carried scalar on the exit path, with
+    // v_readfirstlane of nothing, in every iteration)
+    int c_march = 0, c_block = 0, c_shade = 0, c_bvh = 0, c_leaf = 0;
+    auto census = [&]() {
         if (BVH && __ballot(st == ST_TRACED)) {  // octree part of some traces just ended: entity BVHs next
             const SceneView S = arg_copy(&fresh_args()->S);
             if (st == ST_TRACED) st = rbvh_begin(S, L);
         }
-        // the pool's census: paths waiting for each phase, in lanes and parked
-        const int c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
-        const int c_block = count_lanes(st == ST_BLOCK) + count_lanes(ptag == ST_BLOCK);
-        const int c_shade = count_lanes(st == ST_SHADE) + count_lanes(ptag == ST_SHADE);  // (fresh paths included)
-        const int c_bvh = BVH ? count_lanes(st == ST_BVH) + count_lanes(ptag == ST_BVH) : 0;
-        const int c_leaf = BVH ? count_lanes(st == ST_LEAF) + count_lanes(ptag == ST_LEAF) : 0;
-        if ((c_march | c_block | c_shade | c_bvh | c_leaf) == 0) break;  // every lane and every slot is ST_DONE
+        c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
+        c_block = count_lanes(st == ST_BLOCK) + count_lanes(ptag == ST_BLOCK);
+        c_shade = count_lanes(st == ST_SHADE) + count_lanes(ptag == ST_SHADE);  // (fresh paths included)
+        c_bvh = BVH ? count_lanes(st == ST_BVH) + count_lanes(ptag == ST_BVH) : 0;
+        c_leaf = BVH ? count_lanes(st == ST_LEAF) + count_lanes(ptag == ST_LEAF) : 0;
+    };
+    census();
+    while ((c_march | c_block | c_shade | c_bvh | c_leaf) != 0) {  // until every lane and every slot is ST_DONE
         // at most 64 paths run at once; among phases that can fill the wave SHADE and BLOCK go first (they feed the march)
         const int v_march = (c_march < 64 ? c_march : 64) * kWMarch, v_block = (c_block < 64 ? c_block : 64) * kWBlock,
                   v_shade = (c_shade < 64 ? c_shade : 64) * kWShade;
@@ -664,6 +669,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                 prof[5] += dt;
             }
         }
+        census();
     }
     if (STATS && lane == 0) {
         unsigned long long* stats = fresh_args()->stats;
