@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             // NaN (leaf_exit_distance): as good as never does a marching lane of the wave have one, and the loop then runs
             // without the three guards (+0.7 % on the bench)
             const float ninf = -rt_inf();
-            const bool guard = __ballot(st == ST_MARCH && (L.inv.x == ninf || L.inv.y == ninf || L.inv.z == ninf)) != 0;
+            const bool guard = ((__ballot(L.inv.x == ninf) | __ballot(L.inv.y == ninf) | __ballot(L.inv.z == ninf)) & entered) != 0;  // (masks on the scalar unit)
             if (guard)
                 march_loop<TREE, true, STATS>(Sm, Om, L, marching, to_block, data, level, nm, stay, far_masks, prof);
             else
