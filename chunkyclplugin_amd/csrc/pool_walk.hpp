@@ -37,15 +37,22 @@ DEV int rbvh_finished(const SceneView& S, LaneState& L) {
 }
 DEV int rbvh_pop(const SceneView& S, LaneState& L, PathStacks K) {
     if (L.bvh_top == 0) return rbvh_finished(S, L);
-    L.bvh_top -= 1;
-    L.bvh_cur = K.base[L.bvh_top * K.paths + L.pid];
+    // (L.bvh_top counts in units of the stacks' stride, K.paths: entry e of stack p sits at base[e * paths + p], so a push or a
+    // pop is one add and one LDS access — as a plain height the index was a 64-bit multiply-add per access)
+    L.bvh_top -= K.paths;
+    L.bvh_cur = K.base[(unsigned)L.bvh_top + (unsigned)L.pid];
     return ST_BVH;
 }
 // The first four words of the record a walker is at.  Byte offset of the record off S.bvh_rec:
 DEV unsigned rwalk_record_at(const SceneView& S, int cur) {
-    const int lref = -1 - cur, tri = lref >> 6;
-    // nodes and triangles share one allocation: a 32-bit byte offset off one scalar base, whichever the walker is at
-    return cur >= 0 ? (unsigned)cur << 6 : S.tri_off + (unsigned)tri * 80u;
+    // nodes (64 bytes) and triangles (80) share one allocation: a 32-bit byte offset off one scalar base, whichever the walker is
+    // at — both offsets by shifts and adds (a v_mul_lo_u32 runs at a quarter of the rate), the choice a select, no branch
+    const unsigned tri = (unsigned)~cur >> 6;  // -1 - cur = ~cur
+    unsigned t5, at_tri;  // tri * 80 + tri_off as two v_lshl_add_u32 (written as C the optimiser folds them back into the multiply)
+    asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(t5) : "v"(tri));
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(at_tri) : "v"(t5), "s"(S.tri_off));
+    const unsigned at_node = (unsigned)cur << 6;
+    return cur >= 0 ? at_node : at_tri;
 }
 struct WalkWords {
     int4 r0, r1, r2, r3;
@@ -81,8 +88,8 @@ DEV int rwalk_apply(const SceneView& S, LaneState& L, PathStacks K, const WalkWo
         if (miss1 & miss2) return rbvh_pop(S, L, K);
         const bool go_first = !miss1 & (miss2 | (t1 < t2));  // K/bvh.h:86-103: the first child is the near one only when t1 < t2
         if (!miss1 & !miss2) {
-            K.base[L.bvh_top * K.paths + L.pid] = go_first ? second : first;
-            L.bvh_top += 1;
+            K.base[(unsigned)L.bvh_top + (unsigned)L.pid] = go_first ? second : first;
+            L.bvh_top += K.paths;
         }
         L.bvh_cur = go_first ? first : second;
         return ST_BVH;
