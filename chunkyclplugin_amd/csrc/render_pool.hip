@@ -293,7 +293,7 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
 #define CHUNKY_POOL_PARK 56   // paths parked per wave (LDS: 7 x 16 + 8 bytes each; 6 x 4 waves x 56 fill 158 of 160 KB)
 #endif
 #ifndef CHUNKY_POOL_REFILL
-#define CHUNKY_POOL_REFILL 24 // leave the march loop to refill once this many lanes are free and parked marchers exist
+#define CHUNKY_POOL_REFILL 20 // leave the march loop to refill once this many lanes are free and parked marchers exist (round 6, with the new leave rule: 16 / 20 / 24 = 7 504 / 7 526 / 7 510 headline, 4 170 / 4 140 / 4 075 indoor)
 #endif
 #ifndef CHUNKY_WALK_LEAVE
 #define CHUNKY_WALK_LEAVE 24  // leave the entity-BVH walk once this many lanes have finished theirs
