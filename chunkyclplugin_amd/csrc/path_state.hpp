@@ -634,7 +634,16 @@ DEV f3 cosine_direction(f3 n, float x1, float x2) {
     return f3{ux * tx + vx * ty + n.x * tz, uy * tx + vy * ty + n.y * tz, uz * tx + vz * ty + n.z * tz};
 }
 // vote weights: the phase with the largest (waiting lanes x weight) runs next
-constexpr int kWMarch = 4, kWBlock = 4, kWShade = 4;
+#ifndef CHUNKY_W_MARCH
+#define CHUNKY_W_MARCH 4
+#endif
+#ifndef CHUNKY_W_BLOCK
+#define CHUNKY_W_BLOCK 4
+#endif
+#ifndef CHUNKY_W_SHADE
+#define CHUNKY_W_SHADE 4
+#endif
+constexpr int kWMarch = CHUNKY_W_MARCH, kWBlock = CHUNKY_W_BLOCK, kWShade = CHUNKY_W_SHADE;
 
 // variant bit 0 set = force the reference-layout octree walk (K/octree.h:81-89 as written)
 inline bool use_wide(int variant, const SceneView& S) { return S.wide != nullptr && !(variant & 1); }
