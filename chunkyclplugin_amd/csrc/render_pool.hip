@@ -305,7 +305,10 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
 #define CHUNKY_STAY_LONGER 16      // ... how many lanes emptier the march then runs before the wave leaves it
 #endif
 constexpr int kPoolPark = CHUNKY_POOL_PARK, kPoolRefill = CHUNKY_POOL_REFILL, kWalkLeave = CHUNKY_WALK_LEAVE;
-constexpr int kStayFewParked = CHUNKY_STAY_FEW_PARKED, kStayLonger = CHUNKY_STAY_LONGER;
+#ifndef CHUNKY_STAY_LONGER_BVH
+#define CHUNKY_STAY_LONGER_BVH 6   // ... in the kernels with entity BVHs (16 / 10 / 6 / 0 lanes: entities 225.5 / 227 / 225.6 / 223, the city with its entities 851 / 898 / 921 / 914)
+#endif
+constexpr int kStayFewParked = CHUNKY_STAY_FEW_PARKED, kStayLonger = CHUNKY_STAY_LONGER, kStayLongerBvh = CHUNKY_STAY_LONGER_BVH;
 constexpr int kWWalk = 1;          // vote weight of the walk against kWMarch / kWBlock / kWShade = 4: the walkers are the pool's standing crowd
 constexpr int kSampleBatch = 256;  // sample indices a wave claims per atomic (measured: 64 -20 %, 128 -5 %, 512 -0.1 %, 1024 -1.3 %)
 
@@ -527,7 +530,8 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             // loop (round 6, after the iteration overhead fell): threshold x lanes 12 x 16 = 7 510 / 3 930 / 4 080 Msamples/s on headline / city /
             // indoor against 7 250 / 3 740 / 4 065 without; unconditional (-12 lanes) 7 430 / 3 880 / 4 010 — a scene whose pool is full of
             // marchers (the indoor room) is better off leaving early and refilling.
-            if (parked_march < kStayFewParked) stay -= kStayLonger;
+            // (with entity BVHs the pool is small and the walkers are its standing crowd: 6 lanes — 16 there costs the city with its entities 7 %)
+            if (parked_march < kStayFewParked) stay -= BVH ? kStayLongerBvh : kStayLonger;
             if (K > 0 && parked_march >= kPoolRefill && stay < 65 - kPoolRefill) stay = 65 - kPoolRefill;
             if (stay < 1) stay = 1;
             LaneMask marching = entered, to_block = 0;
