@@ -2081,7 +2081,9 @@ extern "C" int chunky_render_run_ex(chunky_render* r, double* sample_buffer, int
                 if (want < 1) want = 1;
                 if (want > launch_passes || ms > 90.0) launch_passes = want;
                 // where the climb is heading: the rate just measured says how many passes fit 95 ms
-                if (launch_passes >= 8) reserve.set(per_pass > 0.0 && 95.0 / per_pass < (double)merge_interval ? (int)(95.0 / per_pass) + 1 : merge_interval);
+                // (a quarter more than the rate says: the next estimate differs by a few passes, and a launch larger than the array by ONE pass
+                // regrows it — 4.4 GB and 240 ms of hipMalloc in the middle of a warm render, seen on configs[1])
+                if (launch_passes >= 8) reserve.set(per_pass > 0.0 && 119.0 / per_pass < (double)merge_interval ? (int)(119.0 / per_pass) + 1 : merge_interval);
             }
             if (!save && cb.post_render && std::chrono::duration<double, std::milli>(t1 - last_callback).count() > 100.0 &&
                 (!cb.poll_gate || cb.poll_gate(cb.user))) {  // :153-157; the gate is `!manager.shouldFinalize()` (:154)
