@@ -240,6 +240,26 @@ def test_draw_depth_above_16_bits(gpu_instance, port):
     loader.close()
 
 
+def test_path_depth_255_marks_a_fresh_path_so_deeper_renders_take_another_kernel(gpu_instance, port):
+    """render_pool encodes "this lane holds no path" as path depth 255 (round 6: the state of a path is then its class): a maximum
+    depth of 254 still runs it, 255 — the most the option takes — runs render_waves, and both give the C restatement's image at that
+    depth (an indoor room: every path bounces until the limit)."""
+    from oracle.binding import PortOptions
+    sc = gs.make("indoor_sun").with_view(40, 24)
+    seeds = scenes.java_random_ints(2)
+    loader, r = make_renderer(gpu_instance, sc)
+    for depth, pool in ((254, True), (255, False)):
+        r.reset()
+        r.set_option(native.OPT_MAX_DEPTH, depth)
+        r.render_passes(seeds)
+        assert (r.kernel_info()["pool"] >= 0) == pool, (depth, r.kernel_info())
+        with PortOptions(port, max_depth=depth):
+            want = port.render_passes(sc, seeds)
+        assert_radiance(r.read(), want, f"max depth {depth}")
+    r.close()
+    loader.close()
+
+
 @pytest.mark.parametrize("seed,size,entities,sun", [(11, 16, 0, True), (12, 16, 60, True), (13, 32, 30, False),
                                                        (14, 48, 0, True), (15, 16, 24, True), (16, 32, 0, False)])
 def test_seeded_small_worlds_match_oracle(gpu_instance, port, seed, size, entities, sun):
