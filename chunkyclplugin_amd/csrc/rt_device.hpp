@@ -603,11 +603,15 @@ DEV f3 sky_radiance(const SceneView& S, f3 d, f3 throughput, float emittance) {
     // the disc's texel, fetched while the sky's four are on their way; `in_disc` keeps "+= texel" apart from "no add"
     bool in_disc = false;
     f3 add = mk3(0, 0, 0);
-    if ((S.sun_flags & 1) && !(dot(d, S.sw) < 0.5f)) {
+    // The disc test of K/sky.h:42-66 asks 0 <= pi/2 - acos(x) + 0.12 < 0.24, i.e. |asin(x)| <= 0.12, |x| <= 0.1197: a direction with
+    // |x| > 0.125 fails it by 0.005 — thousands of ulps of rt_acos — so such lanes skip the acos (its square root and polynomial
+    // ran whenever ANY lane of a SHADE execution looked within 60 degrees of the sun); the outcome of no lane changes.
+    const float xu = dot(d, S.su);
+    if ((S.sun_flags & 1) && !(dot(d, S.sw) < 0.5f) && rt_fabs(xu) <= 0.125f) {
         const float radius = 0.03f;
         const float width = radius * 4;
         const float width2 = width * 2;
-        float a = RT_PI_2_F - rt_acos(dot(d, S.su)) + width;
+        float a = RT_PI_2_F - rt_acos(xu) + width;
         if (a >= 0 && a < width2) {
             float b = RT_PI_2_F - rt_acos(dot(d, S.sv)) + width;
             if (b >= 0 && b < width2) {
