@@ -123,31 +123,27 @@ RT_FN float rt_asin_poly(float x, float z) {
     p = rt_fma(p, z, 1.6666752422e-1f);
     return rt_fma(p * z, x, x);
 }
+/* (Both ranges through ONE evaluation of the polynomial, its operands selected first: a wave whose lanes fall into both ranges —
+ * the usual case — otherwise runs it twice.  Per value the operations are the same.) */
 RT_FN float rt_asin(float x) {
     float a = rt_fabs(x);
     if (!(a <= 1.0f)) return rt_nan();
-    float r;
-    if (a <= 0.5f) {
-        r = rt_asin_poly(a, a * a);
-    } else {
-        float z = (1.0f - a) * 0.5f;
-        float s = rt_sqrt(z);
-        float t = rt_asin_poly(s, z);
-        /* pi/2 - 2t, with pi/2 split hi+lo so the subtraction keeps the low bits */
-        r = rt_fma(-2.0f, t, 1.5707963705062866f) + -4.371138828673793e-08f;
-    }
+    const int small = a <= 0.5f;
+    const float z = small ? a * a : (1.0f - a) * 0.5f;
+    const float s = small ? a : rt_sqrt(z);
+    const float t = rt_asin_poly(s, z);
+    /* pi/2 - 2t, with pi/2 split hi+lo so the subtraction keeps the low bits */
+    const float r = small ? t : rt_fma(-2.0f, t, 1.5707963705062866f) + -4.371138828673793e-08f;
     return __builtin_copysignf(r, x);
 }
 RT_FN float rt_acos(float x) {
     float a = rt_fabs(x);
     if (!(a <= 1.0f)) return rt_nan();
-    if (a <= 0.5f) {
-        float t = rt_asin_poly(x, x * x);
-        return (1.5707963705062866f - t) + -4.371138828673793e-08f;
-    }
-    float z = (1.0f - a) * 0.5f;
-    float s = rt_sqrt(z);
-    float t = rt_asin_poly(s, z);
+    const int small = a <= 0.5f;
+    const float z = small ? x * x : (1.0f - a) * 0.5f;
+    const float s = small ? x : rt_sqrt(z);
+    const float t = rt_asin_poly(s, z);
+    if (small) return (1.5707963705062866f - t) + -4.371138828673793e-08f;
     if (x > 0.0f) return 2.0f * t;
     return rt_fma(-2.0f, t, 3.1415927410125732f) + -8.742277657347586e-08f;
 }
@@ -183,10 +179,12 @@ RT_FN float rt_atan2(float y, float x) {
         r = 0.0f;
     } else if (ay == rt_inf() && ax == rt_inf()) {
         r = 0.7853981852531433f;
-    } else if (ax >= ay) {
-        r = rt_atan_pos(ay / ax);
     } else {
-        r = 1.5707963705062866f - rt_atan_pos(ax / ay);
+        /* atan(ay/ax) for ax >= ay, pi/2 - atan(ax/ay) otherwise: ONE quotient and ONE evaluation of rt_atan_pos, the operands
+         * selected first (a wave with lanes on both sides otherwise divides twice and runs the polynomial twice) */
+        const int wide = ax >= ay;
+        const float q = rt_atan_pos((wide ? ay : ax) / (wide ? ax : ay));
+        r = wide ? q : 1.5707963705062866f - q;
     }
     if (rt_f2u(x) >> 31) r = 3.1415927410125732f - r; /* x negative (incl. -0) */
     return __builtin_copysignf(r, y);
