@@ -279,9 +279,9 @@ __host__ __device__ inline long long pool_tiles(const ShardView& T, int width, i
     if (T.world != 1) return ((long long)T.n_local + kSampleTile - 1) / kSampleTile;  // runs of T.tile pixels, or (T.tile == 0) the rank's blocks
     return (long long)((width + kTileEdge - 1) >> kTileLog) * ((height + kTileEdge - 1) >> kTileLog);
 }
-// lanes of the wave for which p holds, as a 32-bit scalar (a 64-bit popcount makes the compiler do the
-// vote comparisons on the VALU: there is no 64-bit scalar less-than)
-DEV int count_lanes(bool p) { return (int)__builtin_popcountll(__ballot(p)); }  // one s_bcnt1_i32_b64
+// lanes of the wave for which p holds, as a 32-bit scalar: one s_bcnt1_i32_b64 (the result is cast to int at once — kept as the
+// 64-bit value __builtin_popcountll returns, the comparisons that follow would be 64-bit ones, which the scalar unit lacks)
+DEV int count_lanes(bool p) { return (int)__builtin_popcountll(__ballot(p)); }
 enum : int {
     ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2,  // voted phases (+ ST_BVH)
     ST_BVH = 9,     // at a node of an entity BVH: inner-node visits are voted as one phase,
