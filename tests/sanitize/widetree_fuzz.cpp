@@ -111,9 +111,9 @@ int main(int argc, char** argv) {
                         fprintf(stderr, "round %d: lookup did not end in a leaf\n", r);
                         return 1;
                     }
-                    const uint32_t code = (uint32_t)e & kWideAny;
-                    const int32_t data = code == kWideAny ? 0x7FFFFFFE : (int32_t)(code & kWidePtrMask);
-                    const int level = (e >> 27) & 15;
+                    const uint32_t ptr = (uint32_t)e & kWidePtrMask;  // (entry layout: widetree.hpp)
+                    const int32_t data = ptr == kWidePtrMask ? 0x7FFFFFFE : (int32_t)ptr;
+                    const int level = (e >> kWideLevelShift) & 15;
                     if (!hostile && (data != want_data || level != want_level)) {
                         fprintf(stderr, "round %d: cell (%d,%d,%d): wide (%d, level %d), reference (%d, level %d)\n", r, x, y, z, data, level, want_data, want_level);
                         return 1;
