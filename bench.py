@@ -24,7 +24,13 @@ inside `value`; `value_hbm_resident` is the same samples over the timed region m
 N > 1: one process per GPU, the scene replicated, the image cut into 16x16-pixel blocks dealt round-robin
 (chunky_render_set_shard), no collective on the data path.  Total work is fixed as N grows => "scaling": "strong".
 
-The JSON line also carries:
+STDOUT carries ONE line, last: a summary of the result object under 4000 bytes (compact_line: the contract's keys, roofline,
+cpu_baseline, image_check, other_configs in brief; the driver keeps about 8 KB of stdout, and round 5's 20 KB line could not be
+parsed).  The FULL object described below goes to bench_detail.json beside this script (--detail PATH) and to stderr.
+--config 5 is not a BASELINE configuration: a 128x128-chunk world whose trees do not fit the 256 MiB Infinity Cache, checked
+against rows the CPU oracle renders in the same run (how the design degrades beyond the caches).
+
+The full result object carries:
   roofline     — the contract figure: achieved = ALGORITHMIC bytes per sample of the reference's
                  access stream (counted by the CPU oracle on a row-sample of this same view) x samples per launch /
                  mean launch duration from HIP events on the launch stream, against the 8 TB/s HBM peak.  It is a
