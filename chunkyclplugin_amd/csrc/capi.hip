@@ -970,7 +970,8 @@ static int rebuild_derived(chunky_scene* s) {
     s->aabb_rec.release();
     s->quad_rec.release();
     s->derived_dirty = false;
-    if (B.empty() || M.empty()) return CHUNKY_OK;
+    // (also for an empty block or material palette: block_info then exists with every block marked as one that never hits — a
+    // cube's material would lie outside the palette — and render_pool's sorted block tests rely on its existence)
     DerivedRecords d;
     derive_records(B, M, A, Q, &d);
     HIP_TRY(s->block_info.upload(d.info.data(), d.info.size() * 4, st));

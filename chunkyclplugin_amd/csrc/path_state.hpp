@@ -25,7 +25,7 @@ struct LdsStack {
 // `kind`: 0 full cube, 1 other model, 2 or 3 cannot be hit (air, invisible, ANY_TYPE); the reference
 // layout carries no kinds, so every non-air leaf reports 1 there (the general test handles all types).
 template <int TREE>
-DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind, bool inside = true) {
+DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int& level, int& kind, bool inside = true, int* entry = nullptr) {
     // `inside` false: the cell is not in the world; the lookup then reads cell (0, 0, 0) (callers discard it)
     if (TREE < 16 && !inside) bx = by = bz = 0;
     if (TREE == 0) {
@@ -82,6 +82,7 @@ DEV void leaf_lookup(const SceneView& S, int bx, int by, int bz, int& data, int&
         level = (e >> 26) & 15;
         kind = (unsigned)e >= 0xC0000000u ? 2 : 0;
         data = (int)((unsigned)e & 0x1FFFFFFu);
+        if (entry) *entry = e;  // the whole entry: bit 25 = a model block (types 2, 3), for callers that sort candidates by it
     }
 }
 
@@ -284,6 +285,7 @@ __host__ __device__ inline long long pool_tiles(const ShardView& T, int width, i
 DEV int count_lanes(bool p) { return (int)__builtin_popcountll(__ballot(p)); }
 enum : int {
     ST_MARCH = 0, ST_BLOCK = 1, ST_SHADE = 2,  // voted phases (+ ST_BVH)
+    ST_MODEL = 6,   // render_pool on the re-laid-out tree: the candidate is a model block (ST_BLOCK then means a full cube)
     ST_BVH = 9,     // at a node of an entity BVH: inner-node visits are voted as one phase,
     ST_LEAF = 11,   // the triangle tests of a leaf as another
     ST_TRACED = 10, // octree part of the trace finished (transient)
@@ -415,14 +417,14 @@ DEV unsigned world_edge(const SceneView& S) {
 }
 template <int TREE, bool GUARD = true>
 DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneMask marching, LaneMask& cand_out,
-                    LaneMask& live_out, int& data, int& level, const unsigned edge, const LaneMask* far_masks = nullptr) {
+                    LaneMask& live_out, int& data, int& level, const unsigned edge, const LaneMask* far_masks = nullptr, int* entry = nullptr) {
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
     int bx = floor_to_int(po.x), by = floor_to_int(po.y), bz = floor_to_int(po.z);
     const bool inside = (unsigned)(bx | by | bz) < edge;  // every coordinate in [0, 2^depth): one compare (a negative one has the top bit set)
     const LaneMask live = marching & __ballot(L.steps < O.draw_depth) & __ballot(!(L.dist_march > L.h.distance)) & __ballot(inside);
     int kind;
-    leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, inside);
+    leaf_lookup<TREE>(S, bx, by, bz, data, level, kind, inside, entry);
     const LaneMask hittable = __ballot(kind < 2);
     const LaneMask cand = live & hittable, go = live & ~hittable;
     // render_pool passes the three lane masks "inv > 0" (scalar registers, set when the loop is entered) instead of L.far
@@ -437,13 +439,13 @@ DEV void march_step(const SceneView& S, const RenderOpts& O, LaneState& L, LaneM
     live_out = live;
 }
 
-template <int TREE, int END, bool FARREG = true>
+template <int TREE, int END, bool FARREG = true, int KINDS = kBlockAny>
 DEV int block_phase(const SceneView& S, LaneState& L) {
     f3 pos = L.o + L.d * L.dist_march;
     f3 po = pos + L.d * kOffset;
     int bx = (int)rt_floor(po.x), by = (int)rt_floor(po.y), bz = (int)rt_floor(po.z);
     Hit t = L.h;
-    float dist = block_hit(S, L.cand_data, bx, by, bz, pos, L.d, L.inv, t);
+    float dist = block_hit<KINDS>(S, L.cand_data, bx, by, bz, pos, L.d, L.inv, t);
     if (!L.shadow) {  // a rejected cube has already overwritten the normal (K/block.h:59-60)
         L.h.normal = t.normal;
         L.h.color = t.color;

@@ -309,6 +309,16 @@ constexpr int kPoolPark = CHUNKY_POOL_PARK, kPoolRefill = CHUNKY_POOL_REFILL, kW
 #define CHUNKY_STAY_LONGER_BVH 6   // ... in the kernels with entity BVHs (16 / 10 / 6 / 0 lanes: entities 225.5 / 227 / 225.6 / 223, the city with its entities 851 / 898 / 921 / 914)
 #endif
 constexpr int kStayFewParked = CHUNKY_STAY_FEW_PARKED, kStayLonger = CHUNKY_STAY_LONGER, kStayLongerBvh = CHUNKY_STAY_LONGER_BVH;
+#ifndef CHUNKY_POOL_SPLIT
+#define CHUNKY_POOL_SPLIT 1   // full cubes and model blocks are tested in phases of their own (on the re-laid-out tree, whose leaf entries say which a block is)
+#endif
+#ifndef CHUNKY_W_MODEL
+#define CHUNKY_W_MODEL 4
+#endif
+#ifndef CHUNKY_MODEL_FIRE
+#define CHUNKY_MODEL_FIRE 560  // model blocks are tested once (how many wait) x (iterations since they last were) reaches this
+#endif
+constexpr int kWModel = CHUNKY_W_MODEL, kModelFire = CHUNKY_MODEL_FIRE;
 constexpr int kWWalk = 1;          // vote weight of the walk against kWMarch / kWBlock / kWShade = 4: the walkers are the pool's standing crowd
 constexpr int kSampleBatch = 256;  // sample indices a wave claims per atomic (measured: 64 -20 %, 128 -5 %, 512 -0.1 %, 1024 -1.3 %)
 
@@ -385,7 +395,7 @@ DEV unsigned xcd_claim(int* counters, XcdClaim& c, int& tried, bool need, unsign
 // `to_block`; `data` / `level` are the leaf every lane looked at last.
 template <int TREE, bool GUARD, bool STATS>
 DEV void march_loop(const SceneView& Sm, const RenderOpts& Om, LaneState& L, LaneMask& marching, LaneMask& to_block, int& data, int& level,
-                    int& nm, int stay, const LaneMask* far_masks, unsigned long long* prof) {
+                    int& nm, int stay, const LaneMask* far_masks, unsigned long long* prof, int* entry = nullptr) {
     const unsigned edge = world_edge(Sm);
     do {
         if (STATS) {
@@ -393,7 +403,7 @@ DEV void march_loop(const SceneView& Sm, const RenderOpts& Om, LaneState& L, Lan
             prof[1] += (unsigned long long)nm;
         }
         LaneMask cand, live;
-        march_step<TREE, GUARD>(Sm, Om, L, marching, cand, live, data, level, edge, far_masks);
+        march_step<TREE, GUARD>(Sm, Om, L, marching, cand, live, data, level, edge, far_masks, entry);
         to_block |= cand;
         marching = live & ~cand;
         nm = __popcll(marching);
@@ -404,6 +414,9 @@ template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false>
 __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
     constexpr int WORDS = EXT ? 9 : (BVH ? 8 : 7);  // 16-byte words of a parked path (pool_pack)
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
+    // candidates sorted into full cubes (ST_BLOCK) and model blocks (ST_MODEL); not with entity BVHs or the extended integrator
+    // (their pools are small: measured -4 % / -2 %)
+    constexpr bool SPLIT = CHUNKY_POOL_SPLIT != 0 && TREE != 0 && !BVH && !EXT;
     extern __shared__ int lds[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     PoolLds P{nullptr, nullptr, nullptr};
@@ -465,7 +478,8 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
     // the pool's census: paths waiting for each phase, in lanes and parked (taken at the END of an iteration, so that the loop has
     // one exit, at its head: a break in mid-loop makes the compiler define every loop-carried scalar on the exit path, with
     // v_readfirstlane of nothing, in every iteration)
-    int c_march = 0, c_block = 0, c_shade = 0, c_bvh = 0, c_leaf = 0;
+    int c_march = 0, c_block = 0, c_shade = 0, c_bvh = 0, c_leaf = 0, c_model = 0;
+    int model_age = 0;  // iterations since model blocks were last tested
     auto census = [&]() {
         if (BVH && __ballot(st == ST_TRACED)) {  // octree part of some traces just ended: entity BVHs next
             const SceneView S = arg_copy(&fresh_args()->S);
@@ -474,11 +488,12 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         c_march = count_lanes(st == ST_MARCH) + count_lanes(ptag == ST_MARCH);
         c_block = count_lanes(st == ST_BLOCK) + count_lanes(ptag == ST_BLOCK);
         c_shade = count_lanes(st == ST_SHADE) + count_lanes(ptag == ST_SHADE);  // (fresh paths included)
+        c_model = SPLIT ? count_lanes(st == ST_MODEL) + count_lanes(ptag == ST_MODEL) : 0;
         c_bvh = BVH ? count_lanes(st == ST_BVH) + count_lanes(ptag == ST_BVH) : 0;
         c_leaf = BVH ? count_lanes(st == ST_LEAF) + count_lanes(ptag == ST_LEAF) : 0;
     };
     census();
-    while ((c_march | c_block | c_shade | c_bvh | c_leaf) != 0) {  // until every lane and every slot is ST_DONE
+    while ((c_march | c_block | c_shade | c_bvh | c_leaf | c_model) != 0) {  // until every lane and every slot is ST_DONE
         // at most 64 paths run at once; among phases that can fill the wave SHADE and BLOCK go first (they feed the march)
         const int v_march = (c_march < 64 ? c_march : 64) * kWMarch, v_block = (c_block < 64 ? c_block : 64) * kWBlock,
                   v_shade = (c_shade < 64 ? c_shade : 64) * kWShade;
@@ -488,6 +503,21 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         if (v_shade >= v_best) {
             X = 2;
             v_best = v_shade;
+        }
+        if (SPLIT) {
+            // Model blocks are a phase of their own: their tests cost three times the cube test, and the wave pays for them whenever ONE
+            // lane has a model block.  How long they wait for company: a batch of T paths costs one execution per T arrivals, and
+            // T / 2 slots of the pool while it gathers — the sum is least at T ~ sqrt(arrival rate), and with the rate estimated as
+            // (waiting) / (iterations since the last execution) that is: run once waiting x iterations reaches a constant.  Where model
+            // blocks are common (the city: 7 arrive per iteration) a wave's worth gathers first; where they are rare (the indoor room:
+            // one in 40 iterations) three or four go together.
+            const int v_model = (c_model < 64 ? c_model : 64) * kWModel;
+            model_age += 1;
+            if (v_model > v_best || c_model * model_age >= kModelFire) {
+                X = ST_MODEL;
+                v_best = v_model > v_best ? v_model : v_best;
+                model_age = 0;
+            }
         }
         if (BVH) {  // the walk through the entity BVHs (inner-node and leaf visits together) is one class of the pool
             const int c_walk = c_bvh + c_leaf;
@@ -523,6 +553,10 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             // from the parked marchers.  One bound, fixed on entry: the loop's bookkeeping is one popcount and one compare.
             const int other_b = c_block < 64 ? c_block : 64, other_s = c_shade < 64 ? c_shade : 64;
             int other = other_b > other_s ? other_b : other_s;
+            if (SPLIT) {
+                const int other_m = c_model < 64 ? c_model : 64;
+                other = other > other_m ? other : other_m;
+            }
             // (with entity BVHs the walkers are not counted: they are the pool's standing crowd and wait in any case)
             int stay = (other + nm + 1) >> 1;
             // ... and longer still when hardly any marcher is parked (fewer than kStayFewParked): leaving then means a swap round and a phase
@@ -539,20 +573,21 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             // are not part of a parked path; as three lane masks they cost three v_cndmask per step (round 6: +0.9 %)
             L.far = far_of(L.inv);
             const LaneMask* far_masks = nullptr;
-            int data, level;
+            int data, level, entry = 0;
             // a direction component that is exactly -0 (inv = -inf) is the one case in which the leaf exit has to guard against a
             // NaN (leaf_exit_distance): as good as never does a marching lane of the wave have one, and the loop then runs
             // without the three guards (+0.7 % on the bench)
             const float ninf = -rt_inf();
             const bool guard = ((__ballot(L.inv.x == ninf) | __ballot(L.inv.y == ninf) | __ballot(L.inv.z == ninf)) & entered) != 0;  // (masks on the scalar unit)
             if (guard)
-                march_loop<TREE, true, STATS>(Sm, Om, L, marching, to_block, data, level, nm, stay, far_masks, prof);
+                march_loop<TREE, true, STATS>(Sm, Om, L, marching, to_block, data, level, nm, stay, far_masks, prof, SPLIT ? &entry : nullptr);
             else
-                march_loop<TREE, false, STATS>(Sm, Om, L, marching, to_block, data, level, nm, stay, far_masks, prof);
+                march_loop<TREE, false, STATS>(Sm, Om, L, marching, to_block, data, level, nm, stay, far_masks, prof, SPLIT ? &entry : nullptr);
             const bool found = in_mask(to_block);
             L.cand_data = found ? data : L.cand_data;
             L.cand_level = found ? level : L.cand_level;
-            st = found ? ST_BLOCK : (in_mask(entered & ~marching & ~to_block) ? END : st);
+            const int st_found = SPLIT && (entry & 0x2000000) ? ST_MODEL : ST_BLOCK;  // bit 25 of a leaf entry: a model block (widetree.hpp kWideKindLow)
+            st = found ? st_found : (in_mask(entered & ~marching & ~to_block) ? END : st);
             if (STATS) {
                 prof[0] -= 1;
                 prof[1] -= (unsigned long long)n_exec;
@@ -560,7 +595,14 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         } else if (X == 1) {
             n_exec = count_lanes(st == ST_BLOCK);
             const SceneView S = arg_copy(&fresh_args()->S);
-            if (st == ST_BLOCK) st = block_phase<TREE, END, false>(S, L);
+            if (st == ST_BLOCK) st = block_phase<TREE, END, false, SPLIT ? kBlockCubes : kBlockAny>(S, L);
+        } else if (SPLIT && X == ST_MODEL) {
+            n_exec = count_lanes(st == ST_MODEL);
+            if (STATS) parts.t[8] += (unsigned long long)n_exec;
+            const SceneView S = arg_copy(&fresh_args()->S);
+            asm volatile("; chunky-mark models");  // (comments in the compiled kernel: tools/isa_scratch.py finds the model blocks' phase by them)
+            if (st == ST_MODEL) st = block_phase<TREE, END, false, kBlockModels>(S, L);
+            asm volatile("; chunky-mark models-end");
         } else if (BVH && X == 5) {
             // The walk: inner-node visits and triangle tests are one step function (rwalk_step: the same four 16-byte reads
             // from one array or the other), so a walker is ST_BVH throughout and the loop below counts that one state.  The
@@ -680,6 +722,12 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                     prof[3 * k + 1] += (unsigned long long)n_exec;
                     prof[3 * k + 2] += dt;
                 }
+            if (X == ST_MODEL) {  // the model blocks' phase is profiled with BLOCK; its cycles also as value 23 (22: lanes tested as model blocks)
+                prof[3] += 1;
+                prof[4] += (unsigned long long)n_exec;
+                prof[5] += dt;
+                parts.t[9] += dt;
+            }
             if (X == 5) {  // the entity-BVH walk is profiled with BLOCK
                 prof[3] += 1;
                 prof[4] += (unsigned long long)n_exec;

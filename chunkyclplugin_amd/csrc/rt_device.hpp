@@ -425,15 +425,23 @@ DEV float quad_model_hit_rec(const SceneView& S, int rec, f3 no, f3 dir, Hit& h)
 }
 
 // BlockPalette_intersectBlock — K/block.h:30-118.  bx/by/bz = integer cell of the march point.
+// KINDS: kBlockAny every block type; kBlockCubes / kBlockModels for callers that sorted their candidates into full cubes and model
+// blocks (render_pool, by the model bit of the re-laid-out tree's leaf entries — widetree.cpp annotate_wide_tree — and tests them in
+// phases of their own): the other kind's code is not part of that instantiation, a block of the other kind (there is none: the
+// entries are annotated from the same palette; block_info marks a malformed block as a type that never hits) does not hit.  Both
+// need block_info (capi.hip builds it for every scene).
+enum : int { kBlockAny = 0, kBlockCubes = 1, kBlockModels = 2 };
+template <int KINDS = kBlockAny>
 DEV float block_hit(const SceneView& S, int block, int bx, int by, int bz, f3 pos, f3 dir, f3 inv, Hit& h) {
-    if (block == kAnyType) return rt_nan();
+    if (KINDS == kBlockAny && block == kAnyType) return rt_nan();
     f3 no = (pos - dir * kOffset) - mk3((float)bx, (float)by, (float)bz);
     int type, ptr;
-    if (S.block_info) {
+    if (KINDS != kBlockAny || S.block_info) {
         const int4 a = S.block_info[(unsigned)block], b = S.block_info[(unsigned)block + 1u];
         type = a.x;
         ptr = a.y;
-        if (type == 1) return cube_hit(S, a.z, a.w, b.x, b.y, b.z, no, pos, inv, h, b.w);  // word 7 of a cube: material word 5
+        if (KINDS != kBlockModels && type == 1) return cube_hit(S, a.z, a.w, b.x, b.y, b.z, no, pos, inv, h, b.w);  // word 7 of a cube: material word 5
+        if (KINDS == kBlockCubes) return rt_nan();
         if (b.w != 0) return type == 2 ? aabb_model_hit_rec(S, b.w, no, dir, inv, h) : quad_model_hit_rec(S, b.w, no, dir, h);
     } else {
         type = S.blocks[block];

@@ -20,3 +20,4 @@ def test_hostile_scene_data_never_faults(seed):
     assert proc.returncode == 0, (proc.stdout[-2000:], proc.stderr[-3000:])
     out = json.loads(proc.stdout.strip().splitlines()[-1])
     assert out["rendered"] + out["refused"] == 24 * 5 and out["rendered"] > 0
+    assert out["kernels_differ"] == [], out["kernels_differ"]  # [seed, what was damaged, kernel variant]

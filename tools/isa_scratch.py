@@ -4,8 +4,8 @@
 Compiles csrc/render_pool.hip for gfx950 with the library's flags (+ any -D given), cuts the instantiation's ISA out of hipcc's
 assembly and attributes every `scratch_` instruction to the phase of the state machine its basic block belongs to.  Phases are
 found by landmarks no other phase contains: the march loops hold the `v_cvt_flr_i32_f32` of march_step (inline asm), SHADE the
-non-temporal staging store and the sample-claim atomic, the swap the fourteen `ds_wrxchg_rtn_b64`, BLOCK the block-record read
-(the first `global_load_dwordx4` pair after the swap).  Output: one line per scratch instruction (line, basic block, loop depth
+non-temporal staging store and the sample-claim atomic, the swap the fourteen `ds_wrxchg_rtn_b64`; BLOCK is what lies between
+SHADE and the march loops, the model blocks' phase what lies between two comments render_pool.hip leaves in the compiled kernel.  Output: one line per scratch instruction (line, basic block, loop depth
 as the assembler comments state it, phase) and a count per phase.  CPU only (hipcc cross-compiles)."""
 import os
 import re
@@ -46,11 +46,18 @@ for i, ln in enumerate(body):
         marks.append((i, "SHADE"))
     elif "s_getreg_b32" in ln:
         marks.append((i, "PROLOGUE"))
+    elif "chunky-mark models-end" in ln:
+        marks.append((i, "MODELS-END"))
+    elif "chunky-mark models" in ln:
+        marks.append((i, "MODELS"))
 # BLOCK: everything between the last SHADE landmark and the first MARCH landmark (program order of the compiled kernel)
 last_shade = max((i for i, p in marks if p == "SHADE"), default=0)
 first_march = min((i for i, p in marks if p == "MARCH"), default=len(body))
 first_swap = min((i for i, p in marks if p == "SWAP"), default=0)
 last_swap = max((i for i, p in marks if p == "SWAP"), default=0)
+# (render_pool.hip leaves a comment where the cube test ends and the model-block tests begin)
+first_models = min((i for i, p in marks if p == "MODELS"), default=None)
+last_models = max((i for i, p in marks if p == "MODELS-END"), default=None)
 
 
 def phase_of(i):
@@ -58,6 +65,8 @@ def phase_of(i):
         return "PROLOGUE (before the main loop)"
     if i <= last_swap + 60:
         return "VOTE+SWAP"
+    if first_models is not None and first_models - 40 <= i <= last_models + 40:  # (the phase's code may sit anywhere in program order)
+        return "MODEL (model blocks)"
     if i <= last_shade + 40:
         return "SHADE (incl. new samples, trace_setup)"
     if i < first_march - 120:
