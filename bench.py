@@ -353,7 +353,7 @@ def end_to_end_leg(loader, sc, spp, make_renderer):
 
 
 def kernel_label(info):
-    bvh_tag = ",bvh" if info["bvh"] else ""
+    bvh_tag = ",bvh" if info["bvh"] else (",sorted" if info.get("sorted") else "")  # sorted: full cubes and model blocks in phases of their own
     return ("render_pool<%d,%d%s>+fold_kernel" % (info["tree"], info["pool"], bvh_tag) if info["pool"] >= 0 else
             "render_waves<%d,%d,%s>" % (info["tree"], info["group"], "bvh" if info["bvh"] else "no-bvh"))
 

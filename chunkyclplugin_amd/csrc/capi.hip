@@ -110,6 +110,7 @@ struct chunky_scene {
     bool bvh_dirty = false;
     std::vector<int32_t> host_blocks, host_materials, host_aabbs, host_quads;  // kept to rebuild what is derived from them
     bool derived_dirty = false;                        // block_info, quad_aux, mat8, aabb_rec, quad_rec
+    int model_leaf_permille = 0;                       // octree leaves that are model blocks, per thousand leaves that can be hit (scene_view)
     WideTree wide_meta;  // host copy kept so the kind bits can follow the block palette; nlev == 0 when absent
     bool wide_dirty = false;
     int octree_depth = -1;
@@ -831,6 +832,26 @@ static bool build_quad_aux(const std::vector<int32_t>& B, const std::vector<int3
     return any;
 }
 
+// How common model blocks are in a world: octree leaves whose block is an AABB or quad model (types 2, 3), per thousand leaves that
+// can be hit at all.  render_pool tests full cubes and model blocks in phases of their own where that pays: the model tests cost
+// three times the cube test and a wave runs them whenever ONE lane of a block test has a model block, but a class more costs every
+// iteration of every wave 1 % in bookkeeping.  Measured: the benchmark city (110 per thousand; 58 % of the block tests on its saved
+// view) +2.3 ... +2.8 %, the synthetic outdoor world (10) +0.1 ... +0.5 %, the same world 16 times larger -1.5 %, the indoor room
+// (0.3) -1 %: sorted from 30 per thousand on.  (CHUNKY_OPT_KERNEL bits 8 / 9 force it on / off.)
+constexpr int kSortBlocksPermille = 30;
+static int model_leaf_permille(const std::vector<int32_t>& T, const std::vector<int32_t>& B) {
+    int64_t cubes = 0, models = 0;
+    for (const int32_t v : T) {
+        if (v > 0) continue;  // a branch
+        const int64_t ptr = -(int64_t)v;
+        if (ptr == 0 || ptr + 1 >= (int64_t)B.size()) continue;  // air, ANY_TYPE, a pointer beyond the palette
+        const int32_t type = B[(size_t)ptr];
+        cubes += type == 1;
+        models += type == 2 || type == 3;
+    }
+    return cubes + models > 0 ? (int)(models * 1000 / (cubes + models)) : 0;
+}
+
 // Everything the kernels read that is derived from the four palettes (rt_device.hpp has the layouts):
 //   block_info  per block {type, pointer, 5 material words of a full cube, model record}
 //   mat8        materials at a 32-byte stride (two 16-byte reads instead of five unaligned dwords)
@@ -1283,6 +1304,7 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     v->actor_bvh_empty = (s->actor_empty || !s->actor_bvh.p) ? 1 : 0;
     if (s->wide_dirty && s->wide_meta.nlev > 0) {
         annotate_wide_tree(&s->wide_meta, s->host_blocks.data(), (int64_t)s->host_blocks.size());
+        s->model_leaf_permille = model_leaf_permille(s->host_octree, s->host_blocks);
         HIP_TRY(hipStreamSynchronize(s->ctx->stream));  // queued passes may still read the old copy
         HIP_TRY(s->wide.upload(s->wide_meta.data.data(), s->wide_meta.data.size() * 4, s->ctx->stream));
         s->wide_dirty = false;
@@ -1313,6 +1335,7 @@ static int scene_view(chunky_scene* s, SceneView* v, bool want_emitters = false)
     v->emitters = want_emitters ? (const int4*)s->emitters.p : nullptr;
     v->n_emitters = want_emitters ? (int)(s->host_emitters.size() / 4) : 0;
     v->n_block_ints = (int)(s->host_blocks.size() < 0x7FFFFFFFu ? s->host_blocks.size() : 0x7FFFFFFFu);
+    v->sort_blocks = s->model_leaf_permille >= kSortBlocksPermille ? 1 : 0;
     v->bvh_rec = (const int4*)s->bvh_rec.p;
     v->tri_rec = s->bvh_rec.p ? (const int4*)((const char*)s->bvh_rec.p + s->tri_off) : nullptr;
     v->tri_off = (unsigned)s->tri_off;
@@ -1927,6 +1950,7 @@ extern "C" int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]) {
     out8[3] = r->last_choice.blocks;
     out8[4] = r->last_choice.pool;
     out8[5] = r->last_choice.ext;
+    out8[7] = r->last_choice.sorted;
     if (r->launch_cap > 0) {
         out8[6] = r->launch_cap;  // (of the kernel family that ran last)
     } else {  // before the first launch: what chunky_render_passes is going to decide for this scene and option set

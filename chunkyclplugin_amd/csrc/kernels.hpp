@@ -57,6 +57,7 @@ struct KernelChoice {
     int blocks;  // workgroups launched
     int pool;    // render_pool: paths parked per wave beside the 64 in its lanes; -1 = another kernel
     int ext;     // the extended integrator (CHUNKY_OPT_SUN_SAMPLING / _EMITTERS / _BSDF / _EMITTER_NEE at non-default values)
+    int sorted;  // render_pool: full cubes and model blocks tested in phases of their own
 };
 // render_pool's tiles of 256 pixel slots: the image's 16 x 16-pixel blocks with one rank (edge blocks padded), the rank's own
 // blocks or 256-slot runs with several (path_state.hpp pool_slot_gid)

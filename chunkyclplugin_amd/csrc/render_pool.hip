@@ -309,9 +309,6 @@ constexpr int kPoolPark = CHUNKY_POOL_PARK, kPoolRefill = CHUNKY_POOL_REFILL, kW
 #define CHUNKY_STAY_LONGER_BVH 6   // ... in the kernels with entity BVHs (16 / 10 / 6 / 0 lanes: entities 225.5 / 227 / 225.6 / 223, the city with its entities 851 / 898 / 921 / 914)
 #endif
 constexpr int kStayFewParked = CHUNKY_STAY_FEW_PARKED, kStayLonger = CHUNKY_STAY_LONGER, kStayLongerBvh = CHUNKY_STAY_LONGER_BVH;
-#ifndef CHUNKY_POOL_SPLIT
-#define CHUNKY_POOL_SPLIT 1   // full cubes and model blocks are tested in phases of their own (on the re-laid-out tree, whose leaf entries say which a block is)
-#endif
 #ifndef CHUNKY_W_MODEL
 #define CHUNKY_W_MODEL 4
 #endif
@@ -410,13 +407,16 @@ DEV void march_loop(const SceneView& Sm, const RenderOpts& Om, LaneState& L, Lan
     } while (nm >= stay);
 }
 
-template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false>
+// SORT: full cubes and model blocks are tested in phases of their own (on the re-laid-out tree, whose leaf entries say which a block is);
+// launch_pool picks it for scenes with many model blocks
+template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false, bool SORT = false>
 __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
     constexpr int WORDS = EXT ? 9 : (BVH ? 8 : 7);  // 16-byte words of a parked path (pool_pack)
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
-    // candidates sorted into full cubes (ST_BLOCK) and model blocks (ST_MODEL); not with entity BVHs or the extended integrator
-    // (their pools are small: measured -4 % / -2 %)
-    constexpr bool SPLIT = CHUNKY_POOL_SPLIT != 0 && TREE != 0 && !BVH && !EXT;
+    // candidates sorted into full cubes (ST_BLOCK) and model blocks (ST_MODEL); not instantiated with entity BVHs or the extended
+    // integrator (their pools are small: measured -4 % / -2 %)
+    constexpr bool SPLIT = SORT;
+    static_assert(!SORT || (TREE != 0 && !BVH && !EXT), "sorted block tests: the plain kernel on the re-laid-out tree only");
     extern __shared__ int lds[];
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
     PoolLds P{nullptr, nullptr, nullptr};
@@ -828,6 +828,11 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     typedef void (*Kernel)(WaveArgs);
     Kernel k;
     const bool ext = opts_extended(O);  // EXPERIMENTAL light-transport options: their own instantiations
+    // Block tests sorted by kind (full cubes / model blocks in phases of their own): for scenes in which model blocks are common
+    // (S.sort_blocks, capi.hip scene_view) — the city gains 2 – 3 %, a scene with hardly any pays 1 % for the bookkeeping; variant bit 8
+    // forces it on, bit 9 off (tests and A/B runs); the plain kernel at its full pool only
+    const bool sorted = ((variant & 256) || S.sort_blocks) && !(variant & 512) && !bvh && !ext && tree != 0 && S.block_info != nullptr;
+    bool sorted_ran = false;
     int words = bvh ? 8 : 7;
     if (ext) {
         if (tree != 17 && tree != 18) tree = -1;
@@ -859,11 +864,22 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     } else if (stats) {
         if (tree != 17) tree = -1;
         park = kPoolPark;
-        k = tree == 17 ? render_pool<17, kPoolPark, true> : render_pool<-1, kPoolPark, true>;
+        if (sorted) k = tree == 17 ? render_pool<17, kPoolPark, true, false, false, true> : render_pool<-1, kPoolPark, true, false, false, true>;
+        else k = tree == 17 ? render_pool<17, kPoolPark, true> : render_pool<-1, kPoolPark, true>;
+        sorted_ran = sorted;
     } else if (park != kPoolPark) {
         if (tree != 0) tree = -1;
         if (park == 0) k = tree == 0 ? render_pool<0, 0, false> : render_pool<-1, 0, false>;
         else k = tree == 0 ? render_pool<0, 32, false> : render_pool<-1, 32, false>;
+    } else if (sorted) {
+        switch (tree) {
+            case 16: k = render_pool<16, kPoolPark, false, false, false, true>; break;
+            case 17: k = render_pool<17, kPoolPark, false, false, false, true>; break;
+            case 18: k = render_pool<18, kPoolPark, false, false, false, true>; break;
+            case 19: k = render_pool<19, kPoolPark, false, false, false, true>; break;
+            default: tree = -1; k = render_pool<-1, kPoolPark, false, false, false, true>; break;
+        }
+        sorted_ran = true;
     } else {
         switch (tree) {
             case 0: k = render_pool<0, kPoolPark, false>; break;
@@ -885,7 +901,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     const long long want = (n_samples + (long long)(block / 64) * (64 + park) - 1) / ((long long)(block / 64) * (64 + park));
     int grid = n_cu * bpc;
     if ((long long)grid > want) grid = (int)want;
-    if (chosen) *chosen = KernelChoice{tree, 1, bvh ? 1 : 0, grid, park, ext ? 1 : 0};
+    if (chosen) *chosen = KernelChoice{tree, 1, bvh ? 1 : 0, grid, park, ext ? 1 : 0, sorted_ran ? 1 : 0};
     e = hipMemsetAsync(work_counter, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(work_counter + kXcdCounters, 0, kXcdRanges * sizeof(int), stream);  // the per-XCD sample ranges (xcd_claim)

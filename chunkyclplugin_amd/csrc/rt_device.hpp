@@ -74,6 +74,7 @@ struct SceneView {
     // full cube (K/material.h:31-40), 0} — the block-palette and material-palette reads of
     // K/block.h:36-49 as ONE 32-byte load; built at upload, null when a palette is missing
     const int4* __restrict__ block_info;
+    int sort_blocks;   // model blocks are common in this world: render_pool tests full cubes and model blocks in phases of their own (capi.hip scene_view)
     int n_block_ints;  // ints in the block palette: a leaf whose block pointer lies beyond it never intersects (the wide tree marks such leaves at upload)
     // per quad, at the quad's own int offset in `quads`: {normal xyz, dot(normal, origin), |xv|^2, |yv|^2} — the
     // ray-independent part of K/primitives.h:262-276, evaluated once at upload with this same rt_math.h; null = compute

@@ -259,7 +259,7 @@ class HipPathTracingRenderer:
         out = np.zeros(8, np.int32)
         check(native.lib().chunky_render_kernel_info(self._h, ptr(out)))
         return {"tree": int(out[0]), "group": int(out[1]), "bvh": bool(out[2]), "blocks": int(out[3]), "pool": int(out[4]),
-                "ext": bool(out[5]), "passes_per_launch": int(out[6])}
+                "ext": bool(out[5]), "passes_per_launch": int(out[6]), "sorted": bool(out[7])}
 
     def phase_stats(self, reset: bool = True) -> dict:
         out = np.zeros(24, np.uint64)

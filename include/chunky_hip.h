@@ -169,7 +169,8 @@ typedef enum chunky_option {
                                      * one lane per path (render_lanes), bit 2 phase profile (pool kernel), bit 3 the
                                      * fallback kernel render_waves instead of the pool kernel, bits 4-5 (render_waves)
                                      * lanes per pixel 1/8/16, bits 6-7 (pool kernel) paths parked per wave none/32 instead
-                                     * of 56 (all bit-identical) */
+                                     * of 56, bit 8 / bit 9 (pool kernel) full cubes and model blocks tested in phases of their own: always / never
+                                     * (default: where model blocks are common, from 3 % of the world's leaves on) (all bit-identical) */
     /* EXPERIMENTAL light-transport extensions (the reference has none of them — it gates sun
      * sampling on drawTexture, PackedSun.java:16 / K/sky.h:69, ignores emittersEnabled, and loads material word 5 without
      * using it, K/material.h:38).  Specification: oracle/port.c trace_sample_ext; DESIGN.md section 9.  The defaults are the
@@ -232,7 +233,8 @@ int chunky_render_kernel_time(chunky_render* r, float* total_ms, int* launches);
  * of 8x8x8 nodes; lanes per pixel (0 = one lane per pixel for the whole launch); entity-BVH phases present (K/bvh.h:22-113);
  * workgroups launched; paths parked per wave (pool kernel; -1 = the grouped kernel); extended integrator; the most passes one
  * launch of this target carries (256, fewer when the staged samples of a launch would not fit: chunky_render_passes cuts longer
- * requests into launches of that many); 1 reserved}.  On a group: member 0's launch. */
+ * requests into launches of that many); 1 when the launch tested full cubes and model blocks in phases of their own}.  On a group:
+ * member 0's launch. */
 int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]);
 
 /* Profile of the wave-scheduled kernel, filled only while CHUNKY_OPT_KERNEL has bit 2 set: for each of

@@ -37,8 +37,9 @@ def assert_radiance(got, want, what):
 # CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (render_pool, 56 parked paths per wave, wide-tree
 # lookup), bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes),
 # bit 3 = the fallback kernel render_waves (bits 4-5 = its lanes per pixel forced to 1 / 8 / 16: test_pixel_groups covers them
-# all), bits 6-7 = render_pool with no / 32 parked paths
-VARIANTS = [0, 1, 2, 3, 64, 128, 8, 9, 8 | 16]
+# all), bits 6-7 = render_pool with no / 32 parked paths, bit 8 / bit 9 = render_pool testing full cubes and model blocks in phases
+# of their own always / never (by default: where model blocks are common)
+VARIANTS = [0, 1, 2, 3, 64, 128, 8, 9, 8 | 16, 256, 512]
 
 
 def make_renderer(gpu_instance, sc, variant=0):
@@ -220,6 +221,24 @@ def test_render_loop_options_match_oracle(gpu_instance, port, name, draw, depth,
     assert not np.array_equal(bits(want), bits(port.render_passes(sc, seeds))), "the options changed nothing"
     r.close()
     loader.close()
+
+
+def test_sorted_block_tests_run_where_asked(gpu_instance, port):
+    """render_pool tests full cubes and model blocks in phases of their own where model blocks are common (from 30 per thousand of a
+    world's leaves on: capi.hip model_leaf_permille — the timed city, tests/test_timed_goldens.py; the golden worlds hold 29 and 0);
+    CHUNKY_OPT_KERNEL bit 8 / bit 9 force it.  Every combination renders the oracle's image."""
+    seeds = scenes.java_random_ints(3)
+    for name in ("outdoor", "outdoor_nosun", "indoor_sun"):
+        sc = gs.make(name).with_view(64, 40)
+        want = port.render_passes(sc, seeds)
+        for variant, sorted_ in ((0, False), (256, True), (512, False), (256 | 512, False)):
+            loader, r = make_renderer(gpu_instance, sc, variant)
+            r.render_passes(seeds)
+            info = r.kernel_info()
+            assert info["pool"] == 56 and info["sorted"] == sorted_, (name, variant, info)
+            assert_radiance(r.read(), want, f"{name}, variant {variant}")
+            r.close()
+            loader.close()
 
 
 def test_draw_depth_above_16_bits(gpu_instance, port):

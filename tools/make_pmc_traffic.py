@@ -22,6 +22,7 @@ roof = bench["roofline"]
 name = roof["kernel"]                     # e.g. render_pool<17,56>+fold_kernel or render_pool<17,16,bvh>+fold_kernel
 parts = name[name.index("<") + 1:name.index(">")].split(",")
 tree, pool, bvh = int(parts[0]), int(parts[1]), int(len(parts) > 2 and parts[2] == "bvh")
+sorted_ = len(parts) > 2 and parts[2] == "sorted"
 cycles = c["GRBM_GUI_ACTIVE"] / 8.0      # summed over the 8 XCDs
 tcp_cycles = cycles * 256.0              # one L1 (TCP) per CU
 issue = c["SQ_INSTS_VALU"] * 2 / (cycles * 1024)
@@ -41,7 +42,7 @@ smem = c.get("SQ_INSTS_SMEM", 0.0) / cu_cycles
 regs = None
 try:
     kr = json.load(open(os.path.join(os.path.dirname(target), "kernel_resources.json")))["kernels"]
-    key = "void render_pool<%d, %d, false, %s, false>" % (tree, pool, "true" if bvh else "false")
+    key = "void render_pool<%d, %d, false, %s, false, %s>" % (tree, pool, "true" if bvh else "false", "true" if sorted_ else "false")
     regs = kr.get(key)
 except Exception:
     pass
