@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             if (st == ST_BLOCK) st = block_phase<TREE, END, false, SPLIT ? kBlockCubes : kBlockAny>(S, L);
         } else if (SPLIT && X == ST_MODEL) {
             n_exec = count_lanes(st == ST_MODEL);
-            if (STATS) parts.t[8] += (unsigned long long)n_exec;
+            if (STATS) parts.t[8] += (unsigned long long)n_exec + (1ull << 40);  // value 22 of the profile: lanes, and executions in bits 40 up
             const SceneView S = arg_copy(&fresh_args()->S);
             asm volatile("; chunky-mark models");  // (comments in the compiled kernel: tools/isa_scratch.py finds the model blocks' phase by them)
             if (st == ST_MODEL) st = block_phase<TREE, END, false, kBlockModels>(S, L);
@@ -722,12 +722,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
                     prof[3 * k + 1] += (unsigned long long)n_exec;
                     prof[3 * k + 2] += dt;
                 }
-            if (X == ST_MODEL) {  // the model blocks' phase is profiled with BLOCK; its cycles also as value 23 (22: lanes tested as model blocks)
-                prof[3] += 1;
-                prof[4] += (unsigned long long)n_exec;
-                prof[5] += dt;
-                parts.t[9] += dt;
-            }
+            if (X == ST_MODEL) parts.t[9] += dt;  // the model blocks' phase: value 23 of the profile
             if (X == 5) {  // the entity-BVH walk is profiled with BLOCK
                 prof[3] += 1;
                 prof[4] += (unsigned long long)n_exec;

@@ -271,7 +271,8 @@ class HipPathTracingRenderer:
         d["handover"] = {"execs": int(out[12]), "cycles": int(out[13])}
         d["parts"] = {name: int(out[14 + i]) for i, name in enumerate(
             ("sky", "sampling", "trace_setup", "deposit", "fold", "open_pixel", "hand_out", "new_sample"))}
-        d["model"] = {"lanes": int(out[22]), "cycles": int(out[23])}  # render_pool: the model-block phase
+        # render_pool's sorted instantiation: the model blocks' phase ("block" is then the full cubes alone)
+        d["model"] = {"execs": int(out[22]) >> 40, "lanes": int(out[22]) & ((1 << 40) - 1), "cycles": int(out[23])}
         return d
 
     def preview(self) -> np.ndarray:

@@ -243,7 +243,8 @@ int chunky_render_kernel_info(chunky_render* r, int32_t out8[8]);
  * the sum and the maximum of the wave lifetimes and the number of waves (3 values), then the executions
  * and cycles of the pixel/pass hand-over part of SHADE (2 values), then ten cycle sums of parts of SHADE
  * (sky lookup, direction sampling, trace setup, then the hand-over's deposit, fold, pixel opening, pass hand-out,
- * new sample; two spare): 24 values in all. */
+ * new sample; then, of the pool kernel's phase for model blocks — where it tests them apart from the full cubes, CHUNKY_OPT_KERNEL
+ * bit 8 — lanes (executions in bits 40 up) and cycles): 24 values in all. */
 int chunky_render_phase_stats(chunky_render* r, uint64_t* out24, int reset);
 
 /* Preview kernel (K/rayTracer.cl:115-217; OpenClPreviewRenderer.java:47-115): width*height ARGB ints. */

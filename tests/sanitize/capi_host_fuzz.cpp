@@ -1,6 +1,6 @@
 // tests/sanitize/capi_host_fuzz.cpp — TEST-ONLY: the host-side parsers of csrc/capi.hip that walk caller-supplied ints — derive_records
 // (block / material / AABB / quad palettes -> aligned records), build_quad_aux, build_bvh_records + bvh_leaves_sound (entity BVHs),
-// list_emitters (octree + palettes) — under AddressSanitizer + UBSan on the CPU.  The translation unit is capi.hip itself, compiled for
+// list_emitters and model_leaf_permille (octree + palettes) — under AddressSanitizer + UBSan on the CPU.  The translation unit is capi.hip itself, compiled for
 // the host only; nothing here touches a device (no HIP call is reached: the functions under test are the pure halves).
 //
 // Inputs: palettes and trees that are well formed, and the same with ints damaged at random (pointers outside their palettes, huge and
@@ -285,6 +285,9 @@ static int fuzz_emitters(int rounds) {
         std::vector<int32_t> out;
         list_emitters(&s, &out);
         if (out.size() % 4 != 0 || out.size() / 4 > s.host_octree.size()) return fprintf(stderr, "round %d: emitter list size\n", r), 1;
+        // (the same walk of caller-supplied leaves: how common model blocks are, which picks render_pool's sorted block tests)
+        const int share = model_leaf_permille(s.host_octree, s.host_blocks);
+        if (share < 0 || share > 1000) return fprintf(stderr, "round %d: model share %d\n", r, share), 1;
         listed += (long long)out.size() / 4;
     }
     printf("{\"emitter_rounds\": %d, \"emitters_listed\": %lld}\n", rounds, listed);

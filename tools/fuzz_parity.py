@@ -19,7 +19,7 @@ from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader, 
 from oracle import binding  # noqa: E402
 from oracle.binding import PortCull, PortExt, PortOptions  # noqa: E402
 
-VARIANTS = [0, 0, 0, 0, 1, 2, 3, 64, 128, 8, 9, 8 | 16, 8 | 32, 8 | 48]
+VARIANTS = [0, 0, 0, 256, 256, 512, 1, 2, 3, 64, 128, 8, 9, 8 | 16, 8 | 32, 8 | 48]  # (256 / 512: render_pool's sorted block tests forced on / off)
 
 
 def main():

@@ -40,7 +40,7 @@ w = st.pop("waves")
 ho = st.pop("handover")
 parts = st.pop("parts")
 model = st.pop("model")
-tot = sum(v["cycles"] for v in st.values()) + model["cycles"]
+tot = sum(v["cycles"] for v in st.values()) + model["cycles"]   # (march, block, shade + the model blocks' phase of the sorted kernel)
 out = {"variant": variant, "launch_ms": ms / n, "Msamples/s": samples / (ms / n) / 1e3}
 for k, v in st.items():
     out[k] = {"execs_per_sample": v["execs"] * 64 / samples, "lanes_per_exec": v["lanes"] / max(v["execs"], 1),
@@ -56,7 +56,8 @@ out["parts_share_of_total"] = {k: round(v / max(tot, 1), 4) for k, v in parts.it
 if info["pool"] >= 0:  # render_pool reuses three slots: swap cycles, loop iterations, march-loop entries
     out["parts_share_of_total"].pop("open_pixel"); out["parts_share_of_total"].pop("hand_out")
     out["parts_share_of_total"]["swap"] = out["parts_share_of_total"].pop("fold")
-    out["model"] = {"lanes_per_64_samples": model["lanes"] * 64 / samples, "time_share": model["cycles"] / max(tot, 1)}
+    out["model"] = {"execs_per_sample": model["execs"] * 64 / samples, "lanes_per_exec": model["lanes"] / max(model["execs"], 1),
+                    "cycles_per_exec": model["cycles"] / max(model["execs"], 1), "time_share": model["cycles"] / max(tot, 1)}
     out["loop"] = {"iterations_per_64_samples": parts["open_pixel"] * 64 / samples, "march_entries_per_64_samples": parts["hand_out"] * 64 / samples}
 out["waves"] = {"n": w["n"], "mean_life_over_max": w["life_sum"] / max(w["n"], 1) / max(w["life_max"], 1)}
 print(json.dumps(out, indent=1))
