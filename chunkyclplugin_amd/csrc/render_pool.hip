@@ -156,7 +156,8 @@ DEV int shade_phase_ext(const SceneView& S, const RenderOpts& O, LaneState& L) {
 // rings and hand-over rounds of render_waves (15 % of its time) do not exist here.
 // A lane (or parked slot) that holds no path and wants a sample is "fresh": state ST_SHADE — the SHADE branch serves it — with
 // the path depth 255 (kFreshDepth; launch_pool sends max_depth above 254 to the other kernels).  The states a path can be in
-// between two phase executions are then 0 MARCH, 1 BLOCK, 2 SHADE, 3 DONE (+ ST_BVH / ST_LEAF with entity BVHs): the state IS its
+// between two phase executions are then 0 MARCH, 1 BLOCK, 2 SHADE, 3 DONE (+ ST_BVH / ST_LEAF with entity BVHs, + ST_MODEL where full
+// cubes and model blocks are tested in phases of their own: SORT): the state IS its
 // class, the census is one compare per class, and the vote and the swap need no classification (round 6: a fresh path used to be
 // a state of its own, 12, and every iteration classified both state vectors through a chain of compares and branches).
 constexpr unsigned kFreshDepth = 255u;
