@@ -85,6 +85,32 @@ def test_hip_matches_the_reference_at_timed_sizes(gpu_instance, views, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,variant,sorted_", [("outdoor", 256, True), ("indoor", 256, True), ("city", 512, False)])
+def test_the_other_block_test_order_gives_the_same_rows(gpu_instance, views, name, variant, sorted_):
+    """render_pool tests full cubes and model blocks in phases of their own where model blocks are common (the city) and as they come
+    elsewhere: the instantiation a timed view does NOT run by default (CHUNKY_OPT_KERNEL bit 8 / bit 9) renders the reference
+    build's rows as well."""
+    from chunkyclplugin_amd import native
+    from chunkyclplugin_amd.renderer import HipPathTracingRenderer, HipSceneLoader
+    sc = views(name)
+    loader = HipSceneLoader(gpu_instance)
+    loader.load_packed(sc)
+    r = HipPathTracingRenderer(loader, sc.width, sc.height)
+    r.set_camera(sc.projector_type, sc.camera)
+    r.set_option(native.OPT_KERNEL, variant)
+    r.render_passes(GOLD["seeds"])
+    info = r.kernel_info()
+    assert info["tree"] == 17 and info["pool"] == 56 and info["sorted"] == sorted_, info
+    gids = row_gids(sc, GOLD[name + "_rows"])
+    got = r.read().reshape(-1, 3)[gids]
+    want = GOLD[name + "_res"].reshape(-1, 3)
+    same = (bits(got) == bits(want)).all(axis=1)
+    assert same.all(), f"{name}, variant {variant}: {int((~same).sum())} of {len(gids)} pixels differ from the reference build's rows"
+    r.close()
+    loader.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,passes", [("outdoor", 8), ("city", 4), ("city_entities", 2), ("indoor", 4), ("entities", 2), ("entities4k", 1)])
 def test_hip_matches_the_live_reference_build_on_the_whole_image(gpu_instance, ref, views, name, passes):
     """Where the reference build travelled to the GPU box (oracle/_ref; skipped elsewhere): the WHOLE image of a timed view (1920x1080; 3840x2160 for entities4k) — every pixel, `passes` passes of a java.util.Random stream the committed fixture does not hold — rendered by the reference
