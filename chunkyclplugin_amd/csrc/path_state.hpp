@@ -538,9 +538,10 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
     // Each block below appears once, so a shade round issues it once however the lanes split.
     const bool main_trace = !L.shadow;
     if (!hit) {  // intersectSky (K/kernel.h:26-31); record.emittance = 1 for the main ray (K/rayTracer.cl:95)
-        // a shadow ray's record.emittance is the |dot(sun dir, normal)| stored at its start: nothing writes it during
-        // the shadow trace (the block and triangle tests leave the main record alone for shadow rays)
-        const float e = main_trace ? 1.0f : L.h.emittance;
+        // a shadow ray's record.emittance is the |dot(sun dir, normal)| stored at its start (K/sky.h:90) and nothing writes it during
+        // the trace — nor L.d or the normal: it is evaluated here, from the same operands, instead of being carried through the trace
+        // (render_pool's six-word parked record has no place for it while 1/d and the distance marched are alive)
+        const float e = main_trace ? 1.0f : rt_fabs(dot(L.d, L.h.normal));
         L.radiance = L.radiance + sky_radiance(S, L.d, L.throughput, e);
     }
     part_end<PROF>(pt, PT_SKY);
@@ -592,8 +593,7 @@ DEV int shade_phase(const SceneView& S, const RenderOpts& O, LaneState& L, LdsSt
         a = a * rl;
         if (to_sun) {
             L.d = a;
-            L.h.emittance = rt_fabs(dot(L.d, n));
-            L.shadow = true;
+            L.shadow = true;  // (record.emittance = |dot(L.d, n)|, K/sky.h:90: evaluated where it is read, above)
         } else {
             const float tx = root * cs, ty = root * sn, tz = rt_sqrt(1 - x1);
             const float vx = a.y * n.z - a.z * n.y, vy = a.z * n.x - a.x * n.z, vz = a.x * n.y - a.y * n.x;

@@ -173,20 +173,33 @@ DEV int phase_class(int st) {
     return BVH && st >= ST_BVH ? 5 : st;  // (ST_MARCH 0, ST_BLOCK 1, ST_SHADE 2, ST_DONE 3; the entity walk's states are one class)
 }
 
-// A parked path is WORDS 16-byte words.  7 words without entity BVHs (the march-step count shares word 0 with the flags —
+// A parked path is WORDS 16-byte words.  6 words without entity BVHs (1/d and the distance marched share their registers, and so
+// their word, with the hit's colour and emittance: pool_pack; the march-step count shares word 0 with the flags —
 // launch_pool sends draw depths above 65535 to render_waves — and the candidate block takes the place of the BVH cursor's
 // word); 8 with them; 9 for the extended integrator.  The flag bits sit where LaneState's bit-fields have them.
 template <int WORDS>
 DEV void pool_pack(const LaneState& L, uint4 (&v)[WORDS]) {
-    constexpr int H = WORDS == 7 ? 5 : 6;  // first of the two words of the main record
+    constexpr bool SHORT = WORDS <= 7;         // no entity BVHs: the march-step count shares word 0 with the flags, the candidate block takes the cursor's place
+    constexpr int H = SHORT ? 5 : 6;  // first of the two words of the main record
     const unsigned misc = (unsigned)L.depth | ((unsigned)L.shadow << 8) | ((unsigned)L.oct_hit << 9) | ((unsigned)L.trace_hit << 10) |
                           ((unsigned)L.cand_level << 11) | ((unsigned)L.bvh_which << 15) |
-                          (WORDS == 7 ? (unsigned)L.steps << 16 : ((unsigned)L.pid << 16) | ((unsigned)L.tkind << 24) | ((unsigned)L.after_nee << 26));
+                          (SHORT ? (unsigned)L.steps << 16 : ((unsigned)L.pid << 16) | ((unsigned)L.tkind << 24) | ((unsigned)L.after_nee << 26));
     if (WORDS > 8) v[WORDS - 1] = make_uint4(__float_as_uint(L.pend.x), __float_as_uint(L.pend.y), __float_as_uint(L.pend.z), (unsigned)L.h.spec);
-    v[0] = make_uint4((unsigned)L.sidx, L.rng, misc, WORDS == 7 ? (unsigned)L.cand_data : (unsigned)L.steps);
+    v[0] = make_uint4((unsigned)L.sidx, L.rng, misc, SHORT ? (unsigned)L.cand_data : (unsigned)L.steps);
     v[1] = make_uint4(__float_as_uint(L.radiance.x), __float_as_uint(L.radiance.y), __float_as_uint(L.radiance.z), __float_as_uint(L.throughput.x));
     v[2] = make_uint4(__float_as_uint(L.throughput.y), __float_as_uint(L.throughput.z), __float_as_uint(L.o.x), __float_as_uint(L.o.y));
     v[3] = make_uint4(__float_as_uint(L.o.z), __float_as_uint(L.d.x), __float_as_uint(L.d.y), __float_as_uint(L.d.z));
+    if (WORDS == 6) {
+        // Six words: the march's values (1/d, the distance marched) and the hit's colour and emittance are never alive together — from the
+        // start of a trace to its end colour and emittance are dead (a hit rewrites them before SHADE reads them; a shadow ray's
+        // emittance, |dot(sun direction, normal)|, is evaluated by shade_phase where it is read), from the end of a trace to the start of
+        // the next one 1/d and the distance marched are dead (trace_setup sets both) — so the kernel keeps a hit's colour and emittance
+        // in the registers of 1/d and the distance marched between the block test that hit and SHADE (hit_to_march_registers /
+        // march_registers_to_hit), and a parked path has no word for them.
+        v[4] = make_uint4(__float_as_uint(L.inv.x), __float_as_uint(L.inv.y), __float_as_uint(L.inv.z), __float_as_uint(L.dist_march));
+        v[5] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
+        return;
+    }
     v[4] = make_uint4(__float_as_uint(L.inv.x), __float_as_uint(L.inv.y), __float_as_uint(L.inv.z), __float_as_uint(L.dist_march));
     if (WORDS > 7) v[5] = make_uint4((unsigned)L.bvh_cur, (unsigned)L.bvh_top, __float_as_uint(L.bvh_dist), (unsigned)L.cand_data);
     v[H] = make_uint4(__float_as_uint(L.h.distance), __float_as_uint(L.h.normal.x), __float_as_uint(L.h.normal.y), __float_as_uint(L.h.normal.z));
@@ -194,7 +207,8 @@ DEV void pool_pack(const LaneState& L, uint4 (&v)[WORDS]) {
 }
 template <int WORDS>
 DEV void pool_unpack(LaneState& L, const uint4 (&v)[WORDS]) {
-    constexpr int H = WORDS == 7 ? 5 : 6;
+    constexpr bool SHORT = WORDS <= 7;
+    constexpr int H = SHORT ? 5 : 6;
     if (WORDS > 8) {
         L.pend = mk3(__uint_as_float(v[WORDS - 1].x), __uint_as_float(v[WORDS - 1].y), __uint_as_float(v[WORDS - 1].z));
         L.h.spec = (int)v[WORDS - 1].w;
@@ -202,7 +216,7 @@ DEV void pool_unpack(LaneState& L, const uint4 (&v)[WORDS]) {
     L.sidx = (int)v[0].x; L.rng = v[0].y;
     L.depth = v[0].z & 0xFFu; L.shadow = (v[0].z >> 8) & 1u; L.oct_hit = (v[0].z >> 9) & 1u; L.trace_hit = (v[0].z >> 10) & 1u;
     L.cand_level = (v[0].z >> 11) & 15u; L.bvh_which = (v[0].z >> 15) & 1u;
-    if (WORDS == 7) {
+    if (SHORT) {
         L.steps = (int)(v[0].z >> 16);
         L.cand_data = (int)v[0].w;
     } else {
@@ -217,10 +231,27 @@ DEV void pool_unpack(LaneState& L, const uint4 (&v)[WORDS]) {
     L.d = mk3(__uint_as_float(v[3].y), __uint_as_float(v[3].z), __uint_as_float(v[3].w));
     L.inv = mk3(__uint_as_float(v[4].x), __uint_as_float(v[4].y), __uint_as_float(v[4].z));
     L.dist_march = __uint_as_float(v[4].w);
+    if (WORDS == 6) {
+        L.h.distance = __uint_as_float(v[5].x);
+        L.h.normal = mk3(__uint_as_float(v[5].y), __uint_as_float(v[5].z), __uint_as_float(v[5].w));
+        return;
+    }
     L.h.distance = __uint_as_float(v[H].x);
     L.h.normal = mk3(__uint_as_float(v[H].y), __uint_as_float(v[H].z), __uint_as_float(v[H].w));
     L.h.color = f4{__uint_as_float(v[H + 1].x), __uint_as_float(v[H + 1].y), __uint_as_float(v[H + 1].z), 0.0f};
     L.h.emittance = __uint_as_float(v[H + 1].w);
+}
+
+// The six-word record's register sharing (pool_pack): a block test that ended the trace leaves the hit's colour and emittance where
+// 1/d and the distance marched were, SHADE takes them back.  (After a shadow ray's hit, or a trace that ended in the march, what moves
+// is dead on both sides.)
+DEV void hit_to_march_registers(LaneState& L) {
+    L.inv = mk3(L.h.color.x, L.h.color.y, L.h.color.z);
+    L.dist_march = L.h.emittance;
+}
+DEV void march_registers_to_hit(LaneState& L) {
+    L.h.color = f4{L.inv.x, L.inv.y, L.inv.z, 0.0f};
+    L.h.emittance = L.dist_march;
 }
 
 // LDS traffic between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order; the fence keeps
@@ -240,7 +271,7 @@ DEV void wave_lds_fence() {
 // 16-byte groups in one burst and writes its own over them.
 template <int K, int WORDS = 8>
 DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) {
-    constexpr bool BVH = WORDS == 8 || WORDS == 9;  // (the extended integrator's 9-word record carries the walk's fields too)
+    constexpr bool BVH = WORDS == 8 || WORDS == 9;  // (the extended integrator's 9-word record carries the walk's fields too; 6 / 7 words: no entity BVHs)
     // who trades, as lane masks in scalar registers (mask algebra on the scalar unit; the vector unit only compares)
     constexpr LaneMask kSlots = K >= 64 ? ~0ull : ((1ull << K) - 1ull);            // lane j < K speaks for parked slot j
     const LaneMask m_done = __ballot(st == ST_DONE);
@@ -290,8 +321,11 @@ DEV int pool_swap(PoolLds P, LaneState& L, int& st, int& ptag, int X, int lane) 
 #ifndef CHUNKY_POOL_BVH_WAVES
 #define CHUNKY_POOL_BVH_WAVES 5
 #endif
+#ifndef CHUNKY_POOL_WORDS
+#define CHUNKY_POOL_WORDS 6   // 16-byte words of a parked path without entity BVHs (7 in tuning builds: 1/d and colour side by side)
+#endif
 #ifndef CHUNKY_POOL_PARK
-#define CHUNKY_POOL_PARK 56   // paths parked per wave (LDS: 7 x 16 + 8 bytes each; 6 x 4 waves x 56 fill 158 of 160 KB)
+#define CHUNKY_POOL_PARK (CHUNKY_POOL_WORDS == 6 ? 64 : 56)   // paths parked per wave (LDS: WORDS x 16 + 8 bytes each; 6 x 4 waves x 64 x 104 B fill 156 of 160 KB)
 #endif
 #ifndef CHUNKY_POOL_REFILL
 #define CHUNKY_POOL_REFILL 20 // leave the march loop to refill once this many lanes are free and parked marchers exist (round 6, with the new leave rule: 16 / 20 / 24 = 7 504 / 7 526 / 7 510 headline, 4 170 / 4 140 / 4 075 indoor)
@@ -412,7 +446,7 @@ DEV void march_loop(const SceneView& Sm, const RenderOpts& Om, LaneState& L, Lan
 // launch_pool picks it for scenes with many model blocks
 template <int TREE, int K, bool STATS, bool BVH = false, bool EXT = false, bool SORT = false>
 __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_BVH_WAVES : CHUNKY_POOL_WAVES))) render_pool(WaveArgs unused_by_name) {
-    constexpr int WORDS = EXT ? 9 : (BVH ? 8 : 7);  // 16-byte words of a parked path (pool_pack)
+    constexpr int WORDS = EXT ? 9 : (BVH ? 8 : CHUNKY_POOL_WORDS);  // 16-byte words of a parked path (pool_pack)
     constexpr int END = BVH ? ST_TRACED : ST_SHADE;  // where a lane goes when the octree part of a trace ends
     // candidates sorted into full cubes (ST_BLOCK) and model blocks (ST_MODEL); not instantiated with entity BVHs or the extended
     // integrator (their pools are small: measured -4 % / -2 %)
@@ -431,7 +465,7 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         P.list = P.tags + K;
         stacks.base = (int*)(base + K * 16 * WORDS + K * 8);
         // every parked slot starts fresh (depth 255 in its flag word); with entity BVHs it also owns a to-visit stack
-        if (lane < K) P.park[lane] = make_uint4(0u, 0u, kFreshDepth | (WORDS == 7 ? 0u : (unsigned)(64 + lane) << 16), 0u);
+        if (lane < K) P.park[lane] = make_uint4(0u, 0u, kFreshDepth | (WORDS <= 7 ? 0u : (unsigned)(64 + lane) << 16), 0u);
     }
     LdsStack stack{lds, 0};  // render_waves' per-lane stacks are not used here
     LaneState L;
@@ -596,13 +630,19 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
         } else if (X == 1) {
             n_exec = count_lanes(st == ST_BLOCK);
             const SceneView S = arg_copy(&fresh_args()->S);
-            if (st == ST_BLOCK) st = block_phase<TREE, END, false, SPLIT ? kBlockCubes : kBlockAny>(S, L);
+            if (st == ST_BLOCK) {
+                st = block_phase<TREE, END, false, SPLIT ? kBlockCubes : kBlockAny>(S, L);
+                if (WORDS == 6 && st == END) hit_to_march_registers(L);
+            }
         } else if (SPLIT && X == ST_MODEL) {
             n_exec = count_lanes(st == ST_MODEL);
             if (STATS) parts.t[8] += (unsigned long long)n_exec + (1ull << 40);  // value 22 of the profile: lanes, and executions in bits 40 up
             const SceneView S = arg_copy(&fresh_args()->S);
             asm volatile("; chunky-mark models");  // (comments in the compiled kernel: tools/isa_scratch.py finds the model blocks' phase by them)
-            if (st == ST_MODEL) st = block_phase<TREE, END, false, kBlockModels>(S, L);
+            if (st == ST_MODEL) {
+                st = block_phase<TREE, END, false, kBlockModels>(S, L);
+                if (WORDS == 6 && st == END) hit_to_march_registers(L);
+            }
             asm volatile("; chunky-mark models-end");
         } else if (BVH && X == 5) {
             // The walk: inner-node visits and triangle tests are one step function (rwalk_step: the same four 16-byte reads
@@ -641,7 +681,10 @@ __global__ void __launch_bounds__(256, ((STATS || EXT) ? 4 : (BVH ? CHUNKY_POOL_
             const RenderOpts O = arg_copy(&A->O);
             const bool served = st == ST_SHADE;
             bool fresh = served && L.depth == kFreshDepth;  // holds no path: wants a sample
-            if (served && !fresh) st = EXT ? shade_phase_ext<TREE, BVH>(S, O, L) : shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
+            if (served && !fresh) {
+                if (WORDS == 6) march_registers_to_hit(L);
+                st = EXT ? shade_phase_ext<TREE, BVH>(S, O, L) : shade_phase<TREE, BVH, STATS>(S, O, L, stack, &parts);
+            }
             part_begin<STATS>(&parts);
             if (st == ST_NEXT) {  // the path is finished: its radiance waits in the staging array for fold_kernel
                 // streamed past the caches (nt): written once, read once by fold_kernel; the L2 stays with the tree
@@ -801,7 +844,7 @@ __global__ void __launch_bounds__(256) clear_foreign_kernel(ShardView T, int wid
     a[0] = 0.0f; a[1] = 0.0f; a[2] = 0.0f;
 }
 // ------------------------------------------------------------------------------------ launchers
-// render_pool + fold_kernel.  variant bits 6-7 pick the parked paths per wave: 0 = 56 (default), 1 = none, 2 = 32 (test rigs:
+// render_pool + fold_kernel.  variant bits 6-7 pick the parked paths per wave: 0 = 64 (default), 1 = none, 2 = 32 (test rigs:
 // the generic tree form only).
 static hipError_t launch_pool(int variant, const SceneView& S, const CameraView& C, const RenderOpts& O, const ShardView& T,
                               const PassSeeds& P, float* res, int* work_counter, hipStream_t stream, KernelChoice* chosen,
@@ -829,7 +872,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
     // forces it on, bit 9 off (tests and A/B runs); the plain kernel at its full pool only
     const bool sorted = ((variant & 256) || S.sort_blocks) && !(variant & 512) && !bvh && !ext && tree != 0 && S.block_info != nullptr;
     bool sorted_ran = false;
-    int words = bvh ? 8 : 7;
+    int words = bvh ? 8 : CHUNKY_POOL_WORDS;
     if (ext) {
         if (tree != 17 && tree != 18) tree = -1;
         words = 9;
@@ -916,7 +959,7 @@ static hipError_t launch_pool(int variant, const SceneView& S, const CameraView&
 bool pool_kernel_applies(int variant, const SceneView& S, const RenderOpts& O, bool have_queue_and_staging) {
     const bool any_bvh = !S.world_bvh_empty || !S.actor_bvh_empty;
     // render_pool: always without entity BVHs; with them when they could be re-laid out (rt_device.hpp bvh_rec / tri_rec)
-    // (its 7-word parked record counts march steps in 16 bits: a larger draw depth runs render_waves)
+    // (its 6-word parked record counts march steps in 16 bits: a larger draw depth runs render_waves)
     const bool steps_fit = (any_bvh || opts_extended(O) || O.draw_depth <= 65535) && O.max_depth <= 254;  // (path depth 255 marks a fresh path)
     return !(variant & 2) && !(variant & 8) && have_queue_and_staging && steps_fit &&
            (!any_bvh || (S.bvh_rec && S.tri_rec && S.mat8 && !(variant & 1)));

@@ -169,7 +169,7 @@ typedef enum chunky_option {
                                      * one lane per path (render_lanes), bit 2 phase profile (pool kernel), bit 3 the
                                      * fallback kernel render_waves instead of the pool kernel, bits 4-5 (render_waves)
                                      * lanes per pixel 1/8/16, bits 6-7 (pool kernel) paths parked per wave none/32 instead
-                                     * of 56, bit 8 / bit 9 (pool kernel) full cubes and model blocks tested in phases of their own: always / never
+                                     * of 64, bit 8 / bit 9 (pool kernel) full cubes and model blocks tested in phases of their own: always / never
                                      * (default: where model blocks are common, from 3 % of the world's leaves on) (all bit-identical) */
     /* EXPERIMENTAL light-transport extensions (the reference has none of them — it gates sun
      * sampling on drawTexture, PackedSun.java:16 / K/sky.h:69, ignores emittersEnabled, and loads material word 5 without

@@ -200,7 +200,7 @@ def test_default_line_times_every_baseline_config():
     assert rb["in_value"] and rb["count"] == 1 and rb["to_host_ms"][0] > 0 and line["value_hbm_resident"] >= line["value"]
 
 
-@pytest.mark.parametrize("config,kernel", [(1, "render_pool<17,56,sorted>+fold_kernel"), (3, "render_pool<17,56>+fold_kernel"), (4, "render_pool<17,16,bvh>+fold_kernel")])
+@pytest.mark.parametrize("config,kernel", [(1, "render_pool<17,64,sorted>+fold_kernel"), (3, "render_pool<17,64>+fold_kernel"), (4, "render_pool<17,16,bvh>+fold_kernel")])
 def test_other_baseline_configs_through_the_bench(config, kernel):
     """`bench.py --config n`: the other BASELINE configurations with the same JSON schema, each checking its own image."""
     line = _run_single(["--config", str(config)])

@@ -126,7 +126,7 @@ def test_group_on_the_timed_workload(gpu_instance, port):
     rg.render_passes(seeds, sync=False)
     rg.gather()
     info = rg.kernel_info()
-    assert (info["tree"], info["pool"], info["bvh"], info["passes_per_launch"]) == (17, 56, False, 1024)  # a quarter share: long launches fit
+    assert (info["tree"], info["pool"], info["bvh"], info["passes_per_launch"]) == (17, 64, False, 1024)  # a quarter share: long launches fit
     got = rg.read().reshape(-1, 3)
     rows = (3, 271, 540, 811, 1077)
     gids = np.concatenate([np.arange(y * W, (y + 1) * W) for y in rows]).astype(np.int32)

@@ -34,7 +34,7 @@ def assert_radiance(got, want, what):
     pytest.fail(f"{what}: within {REL_TOL} but not bit-exact ({bad} values differ) — the arithmetic contract is broken")
 
 
-# CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (render_pool, 56 parked paths per wave, wide-tree
+# CHUNKY_OPT_KERNEL variants that must all be bit-identical: 0 = default (render_pool, 64 parked paths per wave, wide-tree
 # lookup), bit 0 = the reference-layout octree walk of K/octree.h:81-89, bit 1 = one lane per path (render_lanes),
 # bit 3 = the fallback kernel render_waves (bits 4-5 = its lanes per pixel forced to 1 / 8 / 16: test_pixel_groups covers them
 # all), bits 6-7 = render_pool with no / 32 parked paths, bit 8 / bit 9 = render_pool testing full cubes and model blocks in phases
@@ -235,7 +235,7 @@ def test_sorted_block_tests_run_where_asked(gpu_instance, port):
             loader, r = make_renderer(gpu_instance, sc, variant)
             r.render_passes(seeds)
             info = r.kernel_info()
-            assert info["pool"] == 56 and info["sorted"] == sorted_, (name, variant, info)
+            assert info["pool"] == 64 and info["sorted"] == sorted_, (name, variant, info)
             assert_radiance(r.read(), want, f"{name}, variant {variant}")
             r.close()
             loader.close()

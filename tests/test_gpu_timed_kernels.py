@@ -55,13 +55,13 @@ def outdoor():
 
 
 def test_headline_kernel_256_passes(gpu_instance, port, outdoor):
-    """bench.py's step: one 256-pass launch of render_pool<17, 56> (+ fold_kernel) over the whole 1080p image."""
+    """bench.py's step: one 256-pass launch of render_pool<17, 64> (+ fold_kernel) over the whole 1080p image."""
     sc = outdoor
     seeds = native.java_random_ints(256)
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 64, False), info
     assert info["blocks"] >= 256 * 4
     compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[::3]), "outdoor 256 passes")
     # the second step of the bench continues the running mean at bufferSpp = 256 (K/rayTracer.cl:109-112)
@@ -91,7 +91,7 @@ def test_outdoor_shard_shares(gpu_instance, port, outdoor, world, passes, group,
     r.render_passes(seeds)
     info = r.kernel_info()
     if variant == 0:
-        assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
+        assert (info["tree"], info["pool"], info["bvh"]) == (17, 64, False), info
     else:
         assert (info["tree"], info["group"], info["bvh"], info["pool"]) == (-1, group, False, -1), info   # the fallback: generic tree form
     own = parallel.owned_gids(sc.width * sc.height, rank, world, 256)
@@ -118,7 +118,7 @@ def test_outdoor_block_shards(gpu_instance, port, outdoor, world, rank, passes):
     r.set_shard(rank, world, 0)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 64, False), info
     own = parallel.owned_gids(n, rank, world, 0, sc.width)
     rows = row_gids(sc, ROWS + (1072,))
     mine = np.intersect1d(rows, own)
@@ -151,7 +151,7 @@ def test_launches_longer_than_the_argument_segment(gpu_instance, port, outdoor, 
     r.kernel_time()
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"], info["passes_per_launch"]) == (17, 56, cap), info
+    assert (info["tree"], info["pool"], info["passes_per_launch"]) == (17, 64, cap), info
     assert r.kernel_time()[1] == 1                                    # one launch
     own = parallel.owned_gids(sc.width * sc.height, rank, world, 0, sc.width)
     mine = np.intersect1d(row_gids(sc, (411, 1003))[::3], own)
@@ -176,20 +176,20 @@ def test_launches_longer_than_the_argument_segment(gpu_instance, port, outdoor, 
 
 
 def test_city_kernel(gpu_instance, port):
-    """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_pool<17, 56> (a 7-bit dense top over one level)."""
+    """BASELINE configs[1]: the reference's benchmark octree (depth 10) at 1920x1080 — render_pool<17, 64> (a 7-bit dense top over one level)."""
     from chunkyclplugin_amd import octree2
     sc = octree2.cached_benchmark_scene(1920, 1080)   # raises when the fixture is missing: never skipped silently
     seeds = native.java_random_ints(64)
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info  # depth 10 = a 7-bit dense top over one 3-bit level
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 64, False), info  # depth 10 = a 7-bit dense top over one 3-bit level
     compare_rows(r, port, sc, seeds, row_gids(sc), "city 64 passes")
     r.set_shard(3, 8, 256)
     r.reset()
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"]) == (17, 56), info
+    assert (info["tree"], info["pool"]) == (17, 64), info
     own = parallel.owned_gids(sc.width * sc.height, 3, 8, 256)
     compare_rows(r, port, sc, seeds, np.intersect1d(row_gids(sc), own), "city share 1/8")
     r.close()
@@ -245,7 +245,7 @@ def test_indoor_kernel(gpu_instance, port):
     loader, r = make(gpu_instance, sc)
     r.render_passes(seeds)
     info = r.kernel_info()
-    assert (info["tree"], info["pool"], info["bvh"]) == (17, 56, False), info
+    assert (info["tree"], info["pool"], info["bvh"]) == (17, 64, False), info
     compare_rows(r, port, sc, seeds, row_gids(sc, ROWS[1::2]), "indoor 32 passes")
     r.close()
     loader.close()

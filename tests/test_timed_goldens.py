@@ -72,7 +72,7 @@ def test_hip_matches_the_reference_at_timed_sizes(gpu_instance, views, name):
     r.render_passes(GOLD["seeds"])
     info = r.kernel_info()
     tree, bvh = TIMED_KERNEL[name]
-    assert (info["tree"], info["bvh"]) == (tree, bvh) and info["pool"] == (56 if not bvh else info["pool"]) and info["pool"] > 0, info
+    assert (info["tree"], info["bvh"]) == (tree, bvh) and info["pool"] == (64 if not bvh else info["pool"]) and info["pool"] > 0, info
     # full cubes and model blocks in phases of their own: where model blocks are common (the city, 11 % of its leaves), never with entity BVHs
     assert info["sorted"] == (name == "city"), info
     gids = row_gids(sc, GOLD[name + "_rows"])
@@ -100,7 +100,7 @@ def test_the_other_block_test_order_gives_the_same_rows(gpu_instance, views, nam
     r.set_option(native.OPT_KERNEL, variant)
     r.render_passes(GOLD["seeds"])
     info = r.kernel_info()
-    assert info["tree"] == 17 and info["pool"] == 56 and info["sorted"] == sorted_, info
+    assert info["tree"] == 17 and info["pool"] == 64 and info["sorted"] == sorted_, info
     gids = row_gids(sc, GOLD[name + "_rows"])
     got = r.read().reshape(-1, 3)[gids]
     want = GOLD[name + "_res"].reshape(-1, 3)

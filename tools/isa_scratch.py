@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 from chunkyclplugin_amd import native  # noqa: E402
 
 args = sys.argv[1:]
-kernel = "render_poolILi17ELi56ELb0ELb0ELb0ELb0EE"  # (render_pool<17, 56, false, false, false, false>; the last flag: sorted block tests)
+kernel = "render_poolILi17ELi64ELb0ELb0ELb0ELb0EE"  # (render_pool<17, 64, false, false, false, false>; the last flag: sorted block tests)
 if "--kernel" in args:
     i = args.index("--kernel")
     kernel = args[i + 1]
