@@ -45,7 +45,7 @@ def test_pmc_summary_is_attached_only_to_its_own_launch_shape():
         assert bench.pmc_entry(c, info, e["passes_per_launch"] + 1, e["samples_per_launch"], 0) is None
         assert bench.pmc_entry(c, info, e["passes_per_launch"], e["samples_per_launch"], 8) is None      # another kernel variant
     # configs 2 and 3 run the same instantiation at the same launch shape: the configuration decides
-    assert bench.pmc_entry(3, {"tree": 17, "group": 1, "bvh": False, "pool": 56}, 256, by[2]["samples_per_launch"], 0)["config"] == 3
+    assert bench.pmc_entry(3, {"tree": 17, "group": 1, "bvh": False, "pool": by[3]["kernel_info"][3]}, 256, by[2]["samples_per_launch"], 0)["config"] == 3
 
 
 def _canned_full_line():
